@@ -1,0 +1,176 @@
+/*
+ * radarays_mi355.h -- C ABI of libradarays_mi355.so
+ *
+ * MI355X (gfx950) implementation of ONE path of uos/radarays_ros: the
+ * per-azimuth multi-bounce radar ray loop of RadarCPU::simulate
+ * (src/radarays_ros/RadarCPU.cpp:155-548), behind the reference's own seam
+ *     virtual sensor_msgs::ImagePtr Radar::simulate(ros::Time)      (include/radarays_ros/Radar.hpp:64)
+ * The reference has no FFI: backends are C++ subclasses of `Radar` chosen at
+ * start-up (src/radar_simulator.cpp:118-176).  A third subclass `RadarHIP`
+ *  marshals the protected state `simulate()` reads
+ * (Radar.hpp:66-105) into the calls below -- plain pointers and sizes only.
+ *
+ * Threading: one rr_ctx is used by one thread at a time; one ctx per GPU.
+ * Errors: every call returns 0 on success, <0 on error; rr_last_error() gives
+ * the text.  No exceptions cross this boundary.  There is NO CPU fallback: if
+ * no HIP device is usable rr_create() fails.
+ */
+#ifndef RADARAYS_MI355_H
+#define RADARAYS_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_ABI_VERSION 1
+
+typedef struct rr_ctx rr_ctx;
+
+/* msg/RadarMaterial.msg:1-4 -- m_params.materials.data[] (Radar.hpp:84) */
+typedef struct rr_material {
+    float velocity;   /* m/ns; 0.3 = air; 0 = nothing is transmitted */
+    float ambient;    /* A in  E * (A + B * cos(theta)^C)  (RadarCPU.cpp:310-316) */
+    float diffuse;    /* B */
+    float specular;   /* C */
+} rr_material;
+
+/* The RadarModelConfig fields (cfg/RadarModel.cfg:11-85) and RadarModel fields
+ * (msg/RadarModel.msg:1-3) that RadarCPU::simulate reads, plus the constants
+ * Radar::Radar fixes (src/radarays_ros/Radar.cpp:22-32). */
+typedef struct rr_config {
+    int32_t n_cells;                 /* RadarModel.cfg:16   rows of the polar image */
+    int32_t n_angles;                /* Radar.cpp:29        400 azimuth columns */
+    int32_t n_reflections;           /* RadarModel.cfg:29   number of ray-cast passes (RadarCPU.cpp:220) */
+    int32_t signal_denoising;        /* RadarModel.cfg:44   0 none 1 triangular 2 gaussian 3 maxwell-boltzmann */
+    int32_t signal_denoising_triangular_width;   /* :46 */
+    int32_t signal_denoising_gaussian_width;     /* :48 */
+    int32_t signal_denoising_mb_width;           /* :50 */
+    int32_t ambient_noise;           /* RadarModel.cfg:60   0 none 1 uniform 2 perlin */
+    int32_t scroll_image;            /* :81 */
+    int32_t record_multi_reflection; /* :83 */
+    int32_t record_multi_path;       /* :82 */
+    int32_t max_waves_per_azimuth;   /* build's own: capacity of the per-azimuth wave queue per pass;
+                                        0 = n_samples * 2^(n_reflections-1) clamped to 65536 */
+    double  resolution;              /* :15  m per range bin */
+    double  energy_max;              /* :32 */
+    double  signal_max;              /* :33 */
+    double  signal_denoising_triangular_mode;    /* :47 */
+    double  signal_denoising_gaussian_mode;      /* :49 */
+    double  signal_denoising_mb_mode;            /* :51 */
+    double  ambient_noise_at_signal_0;           /* :61 */
+    double  ambient_noise_at_signal_1;           /* :62 */
+    double  ambient_noise_energy_max;            /* :63 */
+    double  ambient_noise_energy_min;            /* :64 */
+    double  ambient_noise_energy_loss;           /* :65 */
+    double  multipath_threshold;                 /* :84 */
+    float   wave_energy_threshold;   /* Radar.cpp:24  0.001 */
+    float   theta_min;               /* Radar.cpp:28  0 */
+    float   theta_inc;               /* Radar.cpp:27  -(2 pi)/400 */
+    float   range_max;               /* radar_algorithms.cpp:158  1000 (ray tfar) */
+} rr_config;
+
+/* Counters of the last simulated frame (optional; reading them synchronises). */
+typedef struct rr_stats {
+    uint64_t wave_passes;     /* waves ray-cast, all passes */
+    uint64_t hits;
+    uint64_t signals;
+    uint64_t nodes_visited;   /* only counted when the ctx was put in stats mode */
+    uint64_t tris_tested;
+    uint32_t overflow;        /* 1: wave queue capacity exceeded (frame invalid) */
+    uint32_t pad_;
+} rr_stats;
+
+/* Fills *cfg with the defaults of cfg/RadarModel.cfg + Radar.cpp:22-32. */
+void rr_default_config(rr_config* cfg);
+
+/* Context bound to HIP device `device` (what the RadarCPU/RadarGPU constructor
+ * does with its map handle, RadarCPU.hpp:21-28).  NULL on failure. */
+rr_ctx* rr_create(int device);
+void    rr_destroy(rr_ctx* ctx);
+const char* rr_last_error(const rr_ctx* ctx);   /* ctx may be NULL: create error */
+int     rr_abi_version(void);
+
+/* Replaces rm::import_embree_map (src/radar_simulator.cpp:149): triangle soup
+ * + per-face object id (index into object_materials; NULL -> all 0).  Builds
+ * the BVH on the host and uploads it.  Inputs are copied. */
+int rr_set_mesh(rr_ctx* ctx, const float* verts /*[nv][3]*/, size_t nv,
+                const uint32_t* faces /*[nf][3]*/, size_t nf,
+                const uint32_t* face_object_id /*[nf] or NULL*/);
+
+/* Radar::loadParams (Radar.cpp:220-226): materials, object_materials,
+ * material_id_air. */
+int rr_set_materials(rr_ctx* ctx, const rr_material* materials, size_t n_materials,
+                     const int32_t* object_materials, size_t n_objects,
+                     int32_t material_id_air);
+
+/* Radar::updateDynCfg (Radar.cpp:188-218). */
+int rr_set_config(rr_ctx* ctx, const rr_config* cfg);
+
+/* m_waves_start (RadarCPU.cpp:136-145): beam sample directions in the local
+ * azimuth frame, as sample_cone_local (radar_algorithms.cpp:248-294) returns
+ * them.  The reference draws them from std::random_device, so they are an
+ * input here. */
+int rr_set_beam_samples(rr_ctx* ctx, const float* dirs /*[n][3]*/, size_t n);
+
+/* per-azimuth `random_begin` of the ambient-noise stage (RadarCPU.cpp:472);
+ * [n_angles].  Needed only when ambient_noise != 0. */
+int rr_set_noise_offsets(rr_ctx* ctx, const float* rnd, size_t n);
+
+/* RadarCPU::simulate for azimuths [az_begin, az_end) with sensor pose
+ * Tsm = {quaternion x,y,z,w ; translation x,y,z} (Radar::updateTsm,
+ * Radar.cpp:80-132).  Host buffers, synchronous:
+ *   out_u8  [n_cells][n_angles] row-major, step n_angles  == the mono8
+ *           sensor_msgs::Image of RadarCPU.cpp:555-561; only the columns of
+ *           the simulated azimuths are written.
+ *   out_f32 optional, same layout: the float slice before convertTo(CV_8U).
+ *   stats   optional. */
+int rr_simulate(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_begin, int az_end,
+                uint8_t* out_u8, float* out_f32, rr_stats* stats);
+
+/* Same, asynchronous on `stream` (a hipStream_t; NULL = the ctx's own stream)
+ * with DEVICE buffers.  d_cols_u8 receives the simulated columns column-major:
+ * [az_end-az_begin][n_cells] (this is the block a rank contributes to the
+ * multi-GPU gather).  d_cols_f32 optional, same layout. */
+int rr_simulate_columns_device(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_begin, int az_end,
+                               uint8_t* d_cols_u8, float* d_cols_f32, void* stream);
+
+/* Assemble the mono8 image from column-major columns, applying scroll_image
+ * (RadarCPU.cpp:457): d_img[c][(scroll + a) % n_angles] = d_cols[a][c].
+ * Device buffers, asynchronous on `stream`. */
+int rr_assemble_image_device(rr_ctx* ctx, const uint8_t* d_cols_u8 /*[n_angles][n_cells]*/,
+                             uint8_t* d_img_u8 /*[n_cells][n_angles]*/, void* stream);
+
+/* Convenience: rr_simulate_columns_device for all azimuths into the ctx's own
+ * column buffer + rr_assemble_image_device into d_img_u8.  Asynchronous. */
+int rr_simulate_device(rr_ctx* ctx, const float pose_qxyzw_t[7], uint8_t* d_img_u8, void* stream);
+
+/* Blocks until `stream` (NULL = ctx stream) is idle. */
+int rr_synchronize(rr_ctx* ctx, void* stream);
+
+/* Counters of the last frame (synchronises the ctx stream). */
+int rr_get_stats(rr_ctx* ctx, rr_stats* stats);
+
+/* stats mode: traversal counters (nodes_visited, tris_tested) on/off; off by
+ * default because the counting kernel variant is slower. */
+int rr_set_stats_mode(rr_ctx* ctx, int enable);
+
+/* ---- introspection used by tests / bench ---- */
+/* nearest-hit query for rays given in map coordinates (device traversal). */
+int rr_debug_trace(rr_ctx* ctx, const float* origs /*[n][3]*/, const float* dirs /*[n][3]*/, size_t n,
+                   float* out_t /*[n], <0 = miss*/, uint32_t* out_face /*[n]*/);
+/* BVH facts: nodes, leaf triangles, depth, stack entries needed. */
+int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* depth, uint32_t* stack_need);
+/* average duration (ms) of the trace kernel launches since the last call with
+ * reset!=0, measured with hipEvents on the launch stream when timing mode is
+ * on; also returns the number of launches.  Used by bench.py for roofline. */
+int rr_set_timing_mode(rr_ctx* ctx, int enable);
+int rr_get_kernel_time(rr_ctx* ctx, const char* kernel /* "trace"|"shade"|"scan"|"column"|"assemble" */,
+                       double* total_ms, uint64_t* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -8,7 +8,7 @@ The config object passed in is duck-typed: any object exposing the
 RadarModelConfig field names of cfg/RadarModel.cfg (reference) works, e.g.
 radarays_ros_amd.params.RadarModelConfig.
 """
-import ctypes as C
+import ctypes as C  # noqa: F401 (re-exported for tests)
 import os
 import subprocess
 

@@ -1,0 +1,635 @@
+// rr_api.hip -- C ABI of libradarays_mi355.so (include/radarays_mi355.h):
+// context, buffers, frame orchestration.  No CPU fallback: every compute call
+// runs the gfx950 kernels of rr_kernels.hip or fails with an error string.
+#include "../../include/radarays_mi355.h"
+#include "rr_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace rr {
+void launch_trace(const Params& P, int pass, bool stats, hipStream_t s);
+void launch_shade(const Params& P, int pass, hipStream_t s);
+void launch_scan(const Params& P, int pass, hipStream_t s);
+void launch_column(const Params& P, hipStream_t s);
+void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s);
+void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
+                        float* out_t, uint32_t* out_face, hipStream_t s);
+}  // namespace rr
+
+using namespace rr;
+
+namespace {
+
+std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+}  // namespace
+
+struct rr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene
+    bool have_mesh = false;
+    DevBuf<Node4> d_nodes;
+    DevBuf<TriRec> d_tris;
+    uint64_t n_nodes = 0, n_tris = 0;
+    uint32_t depth = 0, stack_need = 0;
+
+    // params
+    rr_config cfg;
+    bool have_cfg = false;
+    std::vector<rr_material> materials;
+    std::vector<int32_t> object_materials;
+    int32_t material_id_air = 0;
+    bool have_materials = false;
+    std::vector<float> beams;   // xyz
+    std::vector<float> noise;
+    std::vector<float> smear;
+    int smear_mode = 0;
+
+    DevBuf<float4> d_qas, d_beams, d_materials;
+    DevBuf<int32_t> d_objmat;
+    DevBuf<float> d_smear, d_noise;
+    bool tables_dirty = true;
+
+    // frame buffers
+    int buf_seg = 0, buf_cap = 0, buf_sigcap = 0, buf_cells = 0;
+    DevBuf<float4> d_wA[2], d_wB[2];
+    DevBuf<double2> d_wC[2];
+    DevBuf<uint32_t> d_idx[2], d_count[2], d_hit_tri, d_sig_count, d_spill;
+    DevBuf<uint8_t> d_cflag, d_cols_u8;
+    DevBuf<SigRec> d_sigtmp, d_sig;
+    DevBuf<float> d_hit_t, d_cols_f32;
+    DevBuf<Counters> d_counters;
+    int spill_stride = 0, stack_lds = 1;
+
+    bool stats_mode = false, timing = false;
+    std::map<std::string, KernelTimer> timers;
+};
+
+namespace {
+
+int fail(rr_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define RR_HIP(c, expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), -100, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+// radar_algorithms.h:283-351 + RadarCPU.cpp:48-93 (host, same float/double mix)
+void make_smear(const rr_config& cfg, std::vector<float>& w, int& mode)
+{
+    w.clear(); mode = 0;
+    int width = 0; double mfrac = 0.0;
+    if (cfg.signal_denoising == 1) { width = cfg.signal_denoising_triangular_width; mfrac = cfg.signal_denoising_triangular_mode; }
+    else if (cfg.signal_denoising == 2) { width = cfg.signal_denoising_gaussian_width; mfrac = cfg.signal_denoising_gaussian_mode; }
+    else if (cfg.signal_denoising == 3) { width = cfg.signal_denoising_mb_width; mfrac = cfg.signal_denoising_mb_mode; }
+    if (width <= 0) return;
+    mode = (int)(mfrac * width);
+    w.resize((size_t)width);
+    if (cfg.signal_denoising == 3) {
+        const float fm = (float)mode;
+        const float a = (float)((double)fm / M_SQRT2);
+        for (int i = 0; i < width; i++) {
+            const float x = (float)i;
+            const float xx = x * x, aa = a * a, aaa = a * a * a;
+            w[i] = (float)(std::sqrt(2.0 / M_PI) * (double)xx * (double)expf(-xx / (2 * aa)) / (double)aaa);
+        }
+    } else {
+        for (int i = 0; i < width; i++) {
+            float p;
+            if (i <= mode) p = (float)i / (float)mode;
+            else p = (float)(1.0 - (double)(((float)i - (float)mode) / ((float)width - (float)mode)));
+            w[i] = (float)((double)(p * 1.0f) + (1.0 - (double)p) * (double)0.0f);
+        }
+    }
+    float sum = 0.0f;
+    for (int i = 0; i < width; i++) sum += w[i];
+    for (int i = 0; i < width; i++) w[i] /= sum;
+    const double mode_val = w[mode];
+    for (int i = 0; i < width; i++) w[i] = (float)((double)w[i] / mode_val);
+}
+
+int wave_capacity(const rr_config& cfg, int n_beam)
+{
+    long cap = cfg.max_waves_per_azimuth;
+    if (cap <= 0) {
+        cap = n_beam;
+        for (int p = 1; p < cfg.n_reflections && cap < 65536; p++) cap *= 2;
+        cap = std::min<long>(cap, 65536);
+    }
+    cap = std::max<long>(cap, n_beam);
+    return (int)cap;
+}
+
+int signal_capacity(const rr_config& cfg, int n_beam, int cap)
+{
+    long tot = 0, w = n_beam;
+    for (int p = 0; p < cfg.n_reflections; p++) { tot += std::min<long>(w, cap); w = std::min<long>(2 * w, cap); }
+    if (cfg.record_multi_path) tot *= 2;
+    return (int)std::max<long>(tot, 1);
+}
+
+int upload_tables(rr_ctx* c)
+{
+    if (!c->tables_dirty) return 0;
+    const rr_config& g = c->cfg;
+    // Tas.R = EulerAngles{0,0,theta(angle)} -> quaternion (rmagine ZYX), RadarCPU.cpp:202
+    std::vector<float4> qas((size_t)g.n_angles);
+    for (int k = 0; k < g.n_angles; k++) {
+        const float theta = g.theta_min + (float)k * g.theta_inc;
+        const float roll = 0.0f, pitch = 0.0f, yaw = theta;
+        const float cr = cosf(roll / 2.0f), sr = sinf(roll / 2.0f);
+        const float cp = cosf(pitch / 2.0f), sp = sinf(pitch / 2.0f);
+        const float cy = cosf(yaw / 2.0f), sy = sinf(yaw / 2.0f);
+        float4 q;
+        q.w = cr * cp * cy + sr * sp * sy;
+        q.x = sr * cp * cy - cr * sp * sy;
+        q.y = cr * sp * cy + sr * cp * sy;
+        q.z = cr * cp * sy - sr * sp * cy;
+        qas[k] = q;
+    }
+    RR_HIP(c, c->d_qas.ensure(qas.size()));
+    RR_HIP(c, hipMemcpy(c->d_qas.p, qas.data(), qas.size() * sizeof(float4), hipMemcpyHostToDevice));
+
+    const size_t nb = c->beams.size() / 3;
+    std::vector<float4> b4(nb);
+    for (size_t i = 0; i < nb; i++) b4[i] = make_float4(c->beams[3 * i], c->beams[3 * i + 1], c->beams[3 * i + 2], 0.0f);
+    RR_HIP(c, c->d_beams.ensure(nb));
+    if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
+
+    std::vector<float4> m4(c->materials.size());
+    for (size_t i = 0; i < m4.size(); i++)
+        m4[i] = make_float4(c->materials[i].velocity, c->materials[i].ambient, c->materials[i].diffuse, c->materials[i].specular);
+    RR_HIP(c, c->d_materials.ensure(m4.size()));
+    if (!m4.empty()) RR_HIP(c, hipMemcpy(c->d_materials.p, m4.data(), m4.size() * sizeof(float4), hipMemcpyHostToDevice));
+    RR_HIP(c, c->d_objmat.ensure(c->object_materials.size()));
+    if (!c->object_materials.empty())
+        RR_HIP(c, hipMemcpy(c->d_objmat.p, c->object_materials.data(), c->object_materials.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+
+    make_smear(g, c->smear, c->smear_mode);
+    RR_HIP(c, c->d_smear.ensure(c->smear.size()));
+    if (!c->smear.empty()) RR_HIP(c, hipMemcpy(c->d_smear.p, c->smear.data(), c->smear.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    std::vector<float> nz((size_t)g.n_angles, 0.0f);
+    for (size_t i = 0; i < nz.size() && i < c->noise.size(); i++) nz[i] = c->noise[i];
+    RR_HIP(c, c->d_noise.ensure(nz.size()));
+    RR_HIP(c, hipMemcpy(c->d_noise.p, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->tables_dirty = false;
+    return 0;
+}
+
+int ensure_frame_buffers(rr_ctx* c, int n_seg, bool want_f32)
+{
+    const rr_config& g = c->cfg;
+    const int n_beam = (int)(c->beams.size() / 3);
+    const int cap = wave_capacity(g, n_beam);
+    const int sigcap = signal_capacity(g, n_beam, cap);
+    const size_t S = (size_t)n_seg;
+    const size_t per_seg = (size_t)cap * (2 * 2 * 48 + 2 * 4 + 2 * 9 + 8) + (size_t)sigcap * 8 + (size_t)g.n_cells * 5;
+    size_t free_b = 0, total_b = 0;
+    RR_HIP(c, hipMemGetInfo(&free_b, &total_b));
+    if (S * per_seg > total_b / 2)
+        return fail(c, -6, "wave queue capacity needs more than half of device memory; lower max_waves_per_azimuth");
+    for (int k = 0; k < 2; k++) {
+        RR_HIP(c, c->d_wA[k].ensure(S * 2 * cap));
+        RR_HIP(c, c->d_wB[k].ensure(S * 2 * cap));
+        RR_HIP(c, c->d_wC[k].ensure(S * 2 * cap));
+        RR_HIP(c, c->d_idx[k].ensure(S * cap));
+        RR_HIP(c, c->d_count[k].ensure(S));
+    }
+    RR_HIP(c, c->d_cflag.ensure(S * 2 * cap));
+    RR_HIP(c, c->d_sigtmp.ensure(S * 2 * cap));
+    RR_HIP(c, c->d_hit_t.ensure(S * cap));
+    RR_HIP(c, c->d_hit_tri.ensure(S * cap));
+    RR_HIP(c, c->d_sig.ensure(S * sigcap));
+    RR_HIP(c, c->d_sig_count.ensure(S));
+    RR_HIP(c, c->d_counters.ensure(1));
+    RR_HIP(c, c->d_cols_u8.ensure(S * g.n_cells));
+    if (want_f32) RR_HIP(c, c->d_cols_f32.ensure(S * g.n_cells));
+    // traversal stack: LDS part + spill
+    c->stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 24));
+    const int spill_depth = (int)c->stack_need - c->stack_lds;
+    const size_t threads = S * (size_t)((cap + 63) / 64) * 64;
+    c->spill_stride = (int)threads;
+    if (spill_depth > 0) RR_HIP(c, c->d_spill.ensure((size_t)spill_depth * threads));
+    else RR_HIP(c, c->d_spill.ensure(1));
+    c->buf_seg = n_seg; c->buf_cap = cap; c->buf_sigcap = sigcap; c->buf_cells = g.n_cells;
+    return 0;
+}
+
+void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_seg,
+                 uint8_t* d_cols_u8, float* d_cols_f32)
+{
+    const rr_config& g = c->cfg;
+    std::memset(&P, 0, sizeof(P));
+    P.nodes = c->d_nodes.p; P.tris = c->d_tris.p;
+    P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.materials = c->d_materials.p;
+    P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
+    P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
+    for (int k = 0; k < 2; k++) {
+        P.waves[k].A = c->d_wA[k].p; P.waves[k].B = c->d_wB[k].p; P.waves[k].C = c->d_wC[k].p;
+        P.idx[k] = c->d_idx[k].p; P.count[k] = c->d_count[k].p;
+    }
+    P.cflag = c->d_cflag.p; P.sigtmp = c->d_sigtmp.p; P.hit_t = c->d_hit_t.p; P.hit_tri = c->d_hit_tri.p;
+    P.sig = c->d_sig.p; P.sig_count = c->d_sig_count.p; P.spill = c->d_spill.p; P.counters = c->d_counters.p;
+    P.cols_u8 = d_cols_u8; P.cols_f32 = d_cols_f32;
+    P.q_sm = { pose[0], pose[1], pose[2], pose[3] };
+    P.t_sm = { pose[4], pose[5], pose[6] };
+    P.az_begin = az_begin; P.n_seg = n_seg;
+    P.n_beam = (int)(c->beams.size() / 3); P.cap = c->buf_cap; P.sigcap = c->buf_sigcap;
+    P.n_cells = g.n_cells; P.n_angles = g.n_angles;
+    P.n_materials = (int)c->materials.size(); P.n_objects = (int)c->object_materials.size();
+    P.material_id_air = c->material_id_air;
+    P.n_passes = g.n_reflections;
+    P.record_multi_reflection = g.record_multi_reflection; P.record_multi_path = g.record_multi_path;
+    P.signal_denoising = c->smear.empty() ? 0 : g.signal_denoising;
+    P.smear_w = (int)c->smear.size(); P.smear_mode = c->smear_mode;
+    P.ambient_noise = g.ambient_noise; P.scroll = g.scroll_image;
+    P.thr = g.wave_energy_threshold; P.range_max = g.range_max;
+    P.resolution = g.resolution; P.multipath_threshold = g.multipath_threshold;
+    P.energy_max_f = (float)g.energy_max; P.signal_max = g.signal_max;
+    P.noise_at_0 = g.ambient_noise_at_signal_0; P.noise_at_1 = g.ambient_noise_at_signal_1;
+    P.noise_e_max = g.ambient_noise_energy_max; P.noise_e_min = g.ambient_noise_energy_min;
+    P.noise_e_loss = g.ambient_noise_energy_loss;
+    P.spill_stride = c->spill_stride; P.stack_lds = c->stack_lds;
+}
+
+struct TimedScope {
+    rr_ctx* c; hipStream_t s; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    TimedScope(rr_ctx* c_, hipStream_t s_, const char* n_) : c(c_), s(s_), name(n_) {
+        if (c->timing) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    }
+    ~TimedScope() {
+        if (c->timing) { (void)hipEventRecord(b, s); c->timers[name].pending.emplace_back(a, b); }
+    }
+};
+
+int check_ready(rr_ctx* c)
+{
+    if (!c) return -1;
+    if (!c->have_mesh) return fail(c, -2, "rr_set_mesh has not been called");
+    if (!c->have_cfg) return fail(c, -2, "rr_set_config has not been called");
+    if (!c->have_materials) return fail(c, -2, "rr_set_materials has not been called");
+    if (c->beams.empty() && c->cfg.n_reflections > 0) return fail(c, -2, "rr_set_beam_samples has not been called");
+    return 0;
+}
+
+int run_frame(rr_ctx* c, const float pose[7], int az_begin, int az_end,
+              uint8_t* d_cols_u8, float* d_cols_f32, hipStream_t s)
+{
+    const rr_config& g = c->cfg;
+    if (az_begin < 0 || az_end > g.n_angles || az_begin > az_end) return fail(c, -3, "azimuth range out of bounds");
+    const int n_seg = az_end - az_begin;
+    if (n_seg == 0) return 0;
+    for (int k = 0; k < 7; k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
+    int rc = upload_tables(c); if (rc) return rc;
+    const int n_beam = (int)(c->beams.size() / 3);
+    const int cap = wave_capacity(g, n_beam);
+    if (n_seg > c->buf_seg || cap != c->buf_cap || g.n_cells != c->buf_cells ||
+        signal_capacity(g, n_beam, cap) != c->buf_sigcap) {
+        rc = ensure_frame_buffers(c, std::max(n_seg, c->buf_seg), false); if (rc) return rc;
+    }
+    Params P;
+    fill_params(c, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
+    RR_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), s));
+    RR_HIP(c, hipMemsetAsync(c->d_sig_count.p, 0, sizeof(uint32_t) * (size_t)n_seg, s));
+    for (int pass = 0; pass < g.n_reflections; pass++) {
+        { TimedScope t(c, s, "trace"); launch_trace(P, pass, c->stats_mode, s); }
+        { TimedScope t(c, s, "shade"); launch_shade(P, pass, s); }
+        { TimedScope t(c, s, "scan"); launch_scan(P, pass, s); }
+    }
+    { TimedScope t(c, s, "column"); launch_column(P, s); }
+    RR_HIP(c, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int rr_abi_version(void) { return RR_ABI_VERSION; }
+
+void rr_default_config(rr_config* cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->n_cells = 3424; cfg->n_angles = 400; cfg->n_reflections = 4;
+    cfg->signal_denoising = 1;
+    cfg->signal_denoising_triangular_width = 50; cfg->signal_denoising_triangular_mode = 0.35;
+    cfg->signal_denoising_gaussian_width = 50; cfg->signal_denoising_gaussian_mode = 0.5;
+    cfg->signal_denoising_mb_width = 50; cfg->signal_denoising_mb_mode = 0.4;
+    cfg->ambient_noise = 2; cfg->scroll_image = 0;
+    cfg->record_multi_reflection = 1; cfg->record_multi_path = 0;
+    cfg->max_waves_per_azimuth = 0;
+    cfg->resolution = 0.0438; cfg->energy_max = 0.5; cfg->signal_max = 120.0;
+    cfg->ambient_noise_at_signal_0 = 0.3; cfg->ambient_noise_at_signal_1 = 0.03;
+    cfg->ambient_noise_energy_max = 0.5; cfg->ambient_noise_energy_min = 0.1;
+    cfg->ambient_noise_energy_loss = 0.05; cfg->multipath_threshold = 0.5;
+    cfg->wave_energy_threshold = 0.001f;
+    cfg->theta_min = 0.0f; cfg->theta_inc = (float)(-(2 * M_PI) / 400);
+    cfg->range_max = 1000.0f;
+}
+
+rr_ctx* rr_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("rr_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                         "); this library has no CPU fallback";
+        return nullptr;
+    }
+    if (device < 0 || device >= n) { g_create_error = "rr_create: device index out of range"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "rr_create: hipSetDevice failed"; return nullptr; }
+    rr_ctx* c = new rr_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_error = "rr_create: hipStreamCreate failed"; delete c; return nullptr;
+    }
+    rr_default_config(&c->cfg);
+    return c;
+}
+
+void rr_destroy(rr_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
+    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release();
+    for (int k = 0; k < 2; k++) { c->d_wA[k].release(); c->d_wB[k].release(); c->d_wC[k].release(); c->d_idx[k].release(); c->d_count[k].release(); }
+    c->d_hit_tri.release(); c->d_sig_count.release(); c->d_spill.release(); c->d_cflag.release(); c->d_cols_u8.release();
+    c->d_sigtmp.release(); c->d_sig.release(); c->d_hit_t.release(); c->d_cols_f32.release(); c->d_counters.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rr_last_error(const rr_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces, size_t nf,
+                const uint32_t* face_object_id)
+{
+    if (!c) return -1;
+    RR_HIP(c, hipSetDevice(c->device));
+    Bvh4 bvh; std::string err;
+    if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err)) return fail(c, -4, err);
+    RR_HIP(c, hipStreamSynchronize(c->stream));
+    RR_HIP(c, c->d_nodes.ensure(bvh.nodes.size()));
+    RR_HIP(c, hipMemcpy(c->d_nodes.p, bvh.nodes.data(), bvh.nodes.size() * sizeof(Node4), hipMemcpyHostToDevice));
+    RR_HIP(c, c->d_tris.ensure(bvh.tris.size()));
+    if (!bvh.tris.empty())
+        RR_HIP(c, hipMemcpy(c->d_tris.p, bvh.tris.data(), bvh.tris.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+    c->n_nodes = bvh.nodes.size(); c->n_tris = bvh.tris.size();
+    c->depth = bvh.depth; c->stack_need = bvh.stack_need;
+    c->have_mesh = true;
+    c->buf_seg = 0;   // stack geometry may have changed
+    return 0;
+}
+
+int rr_set_materials(rr_ctx* c, const rr_material* materials, size_t n_materials,
+                     const int32_t* object_materials, size_t n_objects, int32_t material_id_air)
+{
+    if (!c) return -1;
+    if (!materials || n_materials == 0) return fail(c, -3, "rr_set_materials: empty material table");
+    if (n_objects && !object_materials) return fail(c, -3, "rr_set_materials: null object_materials");
+    if (material_id_air < 0 || (size_t)material_id_air >= n_materials) return fail(c, -3, "rr_set_materials: material_id_air out of range");
+    for (size_t i = 0; i < n_objects; i++)
+        if (object_materials[i] < 0 || (size_t)object_materials[i] >= n_materials)
+            return fail(c, -3, "rr_set_materials: object_materials entry out of range");
+    c->materials.assign(materials, materials + n_materials);
+    c->object_materials.assign(object_materials, object_materials + n_objects);
+    c->material_id_air = material_id_air;
+    c->have_materials = true; c->tables_dirty = true;
+    return 0;
+}
+
+int rr_set_config(rr_ctx* c, const rr_config* cfg)
+{
+    if (!c) return -1;
+    if (!cfg) return fail(c, -3, "rr_set_config: null config");
+    if (cfg->n_cells < 1 || cfg->n_cells > 8192) return fail(c, -3, "rr_set_config: n_cells must be in [1, 8192]");
+    if (cfg->n_angles < 1 || cfg->n_angles > 65536) return fail(c, -3, "rr_set_config: n_angles must be in [1, 65536]");
+    if (cfg->n_reflections < 0 || cfg->n_reflections > 16) return fail(c, -3, "rr_set_config: n_reflections must be in [0, 16]");
+    if (cfg->signal_denoising < 0 || cfg->signal_denoising > 3) return fail(c, -3, "rr_set_config: signal_denoising must be 0..3");
+    const int w = cfg->signal_denoising == 1 ? cfg->signal_denoising_triangular_width
+                : cfg->signal_denoising == 2 ? cfg->signal_denoising_gaussian_width
+                : cfg->signal_denoising == 3 ? cfg->signal_denoising_mb_width : 0;
+    if (w < 0 || w > 256) return fail(c, -3, "rr_set_config: smear width must be in [0, 256]");
+    if (cfg->ambient_noise < 0 || cfg->ambient_noise > 2) return fail(c, -3, "rr_set_config: ambient_noise must be 0..2");
+    if (!(cfg->resolution > 0.0)) return fail(c, -3, "rr_set_config: resolution must be > 0");
+    c->cfg = *cfg;
+    c->have_cfg = true; c->tables_dirty = true;
+    return 0;
+}
+
+int rr_set_beam_samples(rr_ctx* c, const float* dirs, size_t n)
+{
+    if (!c) return -1;
+    if (n && !dirs) return fail(c, -3, "rr_set_beam_samples: null dirs");
+    if (n > 65536) return fail(c, -3, "rr_set_beam_samples: more than 65536 samples");
+    for (size_t i = 0; i < 3 * n; i++) if (!std::isfinite(dirs[i])) return fail(c, -3, "rr_set_beam_samples: non-finite direction");
+    c->beams.assign(dirs, dirs + 3 * n);
+    c->tables_dirty = true;
+    return 0;
+}
+
+int rr_set_noise_offsets(rr_ctx* c, const float* rnd, size_t n)
+{
+    if (!c) return -1;
+    if (n && !rnd) return fail(c, -3, "rr_set_noise_offsets: null pointer");
+    c->noise.assign(rnd, rnd + n);
+    c->tables_dirty = true;
+    return 0;
+}
+
+int rr_simulate_columns_device(rr_ctx* c, const float pose[7], int az_begin, int az_end,
+                               uint8_t* d_cols_u8, float* d_cols_f32, void* stream)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!pose || !d_cols_u8) return fail(c, -3, "rr_simulate_columns_device: null pose/output");
+    RR_HIP(c, hipSetDevice(c->device));
+    return run_frame(c, pose, az_begin, az_end, d_cols_u8, d_cols_f32, stream ? (hipStream_t)stream : c->stream);
+}
+
+int rr_assemble_image_device(rr_ctx* c, const uint8_t* d_cols_u8, uint8_t* d_img_u8, void* stream)
+{
+    if (!c) return -1;
+    if (!c->have_cfg) return fail(c, -2, "rr_set_config has not been called");
+    if (!d_cols_u8 || !d_img_u8) return fail(c, -3, "rr_assemble_image_device: null buffer");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    { TimedScope t(c, s, "assemble"); launch_assemble_u8(d_cols_u8, d_img_u8, c->cfg.n_angles, c->cfg.n_cells, c->cfg.scroll_image, s); }
+    RR_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* stream)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!pose || !d_img_u8) return fail(c, -3, "rr_simulate_device: null pose/output");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = upload_tables(c); if (rc) return rc;
+    if (c->buf_seg < c->cfg.n_angles) { rc = ensure_frame_buffers(c, c->cfg.n_angles, false); if (rc) return rc; }
+    RR_HIP(c, c->d_cols_u8.ensure((size_t)c->cfg.n_angles * c->cfg.n_cells));
+    rc = run_frame(c, pose, 0, c->cfg.n_angles, c->d_cols_u8.p, nullptr, s); if (rc) return rc;
+    return rr_assemble_image_device(c, c->d_cols_u8.p, d_img_u8, s);
+}
+
+int rr_synchronize(rr_ctx* c, void* stream)
+{
+    if (!c) return -1;
+    RR_HIP(c, hipSetDevice(c->device));
+    RR_HIP(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+    return 0;
+}
+
+int rr_get_stats(rr_ctx* c, rr_stats* st)
+{
+    if (!c || !st) return -1;
+    RR_HIP(c, hipSetDevice(c->device));
+    RR_HIP(c, hipDeviceSynchronize());
+    std::memset(st, 0, sizeof(*st));
+    if (!c->d_counters.p) return 0;
+    Counters h;
+    RR_HIP(c, hipMemcpy(&h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    st->wave_passes = h.wave_passes; st->hits = h.hits; st->signals = h.signals;
+    st->nodes_visited = h.nodes; st->tris_tested = h.tris; st->overflow = h.overflow;
+    return 0;
+}
+
+int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
+                uint8_t* out_u8, float* out_f32, rr_stats* stats)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!pose || (!out_u8 && !out_f32)) return fail(c, -3, "rr_simulate: null pose/output");
+    RR_HIP(c, hipSetDevice(c->device));
+    const rr_config& g = c->cfg;
+    if (az_begin < 0 || az_end > g.n_angles || az_begin > az_end) return fail(c, -3, "azimuth range out of bounds");
+    const int n_seg = az_end - az_begin;
+    if (n_seg == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return 0; }
+    rc = upload_tables(c); if (rc) return rc;
+    rc = ensure_frame_buffers(c, std::max(n_seg, c->buf_seg), out_f32 != nullptr); if (rc) return rc;
+    if (out_f32) RR_HIP(c, c->d_cols_f32.ensure((size_t)c->buf_seg * g.n_cells));
+    rc = run_frame(c, pose, az_begin, az_end, c->d_cols_u8.p, out_f32 ? c->d_cols_f32.p : nullptr, c->stream);
+    if (rc) return rc;
+    std::vector<uint8_t> h8((size_t)n_seg * g.n_cells);
+    std::vector<float> hf(out_f32 ? (size_t)n_seg * g.n_cells : 0);
+    RR_HIP(c, hipMemcpyAsync(h8.data(), c->d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
+    if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), c->d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RR_HIP(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < n_seg; s++) {
+        const int col = (g.scroll_image + az_begin + s) % g.n_angles;   // RadarCPU.cpp:457
+        for (int i = 0; i < g.n_cells; i++) {
+            if (out_u8) out_u8[(size_t)i * g.n_angles + col] = h8[(size_t)s * g.n_cells + i];
+            if (out_f32) out_f32[(size_t)i * g.n_angles + col] = hf[(size_t)s * g.n_cells + i];
+        }
+    }
+    rr_stats st;
+    rc = rr_get_stats(c, &st); if (rc) return rc;
+    if (stats) *stats = st;
+    if (st.overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
+    if (st.overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
+    return 0;
+}
+
+int rr_set_stats_mode(rr_ctx* c, int enable) { if (!c) return -1; c->stats_mode = enable != 0; return 0; }
+int rr_set_timing_mode(rr_ctx* c, int enable) { if (!c) return -1; c->timing = enable != 0; return 0; }
+
+int rr_get_kernel_time(rr_ctx* c, const char* kernel, double* total_ms, uint64_t* launches, int reset)
+{
+    if (!c || !kernel) return -1;
+    RR_HIP(c, hipSetDevice(c->device));
+    RR_HIP(c, hipDeviceSynchronize());
+    KernelTimer& t = c->timers[kernel];
+    for (auto& p : t.pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t.total_ms += ms; t.launches++; }
+        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+    }
+    t.pending.clear();
+    if (total_ms) *total_ms = t.total_ms;
+    if (launches) *launches = t.launches;
+    if (reset) { t.total_ms = 0.0; t.launches = 0; }
+    return 0;
+}
+
+int rr_get_bvh_info(rr_ctx* c, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* depth, uint32_t* stack_need)
+{
+    if (!c) return -1;
+    if (!c->have_mesh) return fail(c, -2, "rr_set_mesh has not been called");
+    if (n_nodes) *n_nodes = c->n_nodes;
+    if (n_tris) *n_tris = c->n_tris;
+    if (depth) *depth = c->depth;
+    if (stack_need) *stack_need = c->stack_need;
+    return 0;
+}
+
+int rr_debug_trace(rr_ctx* c, const float* origs, const float* dirs, size_t n, float* out_t, uint32_t* out_face)
+{
+    if (!c) return -1;
+    if (!c->have_mesh) return fail(c, -2, "rr_set_mesh has not been called");
+    if (n == 0) return 0;
+    if (!origs || !dirs || !out_t || !out_face) return fail(c, -3, "rr_debug_trace: null pointer");
+    RR_HIP(c, hipSetDevice(c->device));
+    const size_t chunk = 1u << 16;
+    const int stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 24));
+    const int spill_depth = (int)c->stack_need - stack_lds;
+    DevBuf<float> d_o, d_d, d_t; DevBuf<uint32_t> d_f, d_spill;
+    RR_HIP(c, d_o.ensure(3 * chunk)); RR_HIP(c, d_d.ensure(3 * chunk)); RR_HIP(c, d_t.ensure(chunk));
+    RR_HIP(c, d_f.ensure(chunk)); RR_HIP(c, d_spill.ensure(spill_depth > 0 ? (size_t)spill_depth * chunk : 1));
+    Params P; std::memset(&P, 0, sizeof(P));
+    P.nodes = c->d_nodes.p; P.tris = c->d_tris.p; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
+    P.spill = d_spill.p; P.spill_stride = (int)chunk; P.stack_lds = stack_lds;
+    int rc = 0;
+    for (size_t b = 0; b < n && !rc; b += chunk) {
+        const size_t m = std::min(chunk, n - b);
+        hipError_t e = hipMemcpy(d_o.p, origs + 3 * b, 3 * m * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_d.p, dirs + 3 * b, 3 * m * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) { launch_debug_trace(P, d_o.p, d_d.p, (int)m, d_t.p, d_f.p, c->stream); e = hipStreamSynchronize(c->stream); }
+        if (e == hipSuccess) e = hipMemcpy(out_t + b, d_t.p, m * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(out_face + b, d_f.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, -100, std::string("rr_debug_trace: ") + hipGetErrorString(e));
+    }
+    d_o.release(); d_d.release(); d_t.release(); d_f.release(); d_spill.release();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// rr_bvh.h -- host-side builder of the 4-wide BVH the HIP traversal kernel walks.
+//
+// Replaces rm::import_embree_map / Embree's BVH (reference
+// src/radar_simulator.cpp:149; rmagine+Embree are not part of the reference
+// tree).  Layout is chosen for MI355X: one node = 128 B = one L2 cache line,
+// child boxes stored SoA so a lane fetches it with 8 dwordx4 loads; triangles
+// are 48 B (3 x float4) in leaf order so a leaf is one contiguous run.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rr {
+
+// child reference encoding
+//   inner : node index (< 0x80000000)
+//   leaf  : 0x80000000 | (count-1) << 28 | first_triangle   (count 1..8, first < 2^28)
+//   empty : box = (+inf, -inf), ref = kEmptyRef
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kEmptyRef = 0x7FFFFFFFu;
+constexpr uint32_t kMaxLeafTris = 4;
+
+struct alignas(16) Node4 {
+    float lo_x[4], lo_y[4], lo_z[4];
+    float hi_x[4], hi_y[4], hi_z[4];
+    uint32_t child[4];
+    uint32_t meta[4];   // meta[0] = number of used children; rest reserved
+};
+static_assert(sizeof(Node4) == 128, "Node4 must be one 128-byte line");
+
+struct alignas(16) TriRec {
+    float v0[3]; uint32_t face;    // original face index (tie-break + normal lookup)
+    float e1[3]; uint32_t object;  // rmagine object/geometry id -> object_materials[]
+    float e2[3]; uint32_t pad;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+struct Bvh4 {
+    std::vector<Node4> nodes;   // nodes[0] is the root
+    std::vector<TriRec> tris;   // leaf order
+    uint32_t depth = 0;         // node levels on the longest root->leaf path
+    uint32_t stack_need = 0;    // upper bound of traversal stack entries
+    float inflate = 0.f;        // outward padding applied to every box
+    float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};
+    double sah_cost = 0.0;
+    double build_seconds = 0.0;
+};
+
+// Builds a binned-SAH binary BVH (multi-threaded), collapses it to 4-wide.
+// Returns false and sets err on invalid input.
+bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
+                const uint32_t* face_object, Bvh4& out, std::string& err, int n_threads = 0);
+
+}  // namespace rr

@@ -1,0 +1,112 @@
+// rr_device.h -- device-side data layout and per-hit radar math (gfx950).
+//
+// Arithmetic note: the reference CPU path is compiled without FMA contraction
+// (CMakeLists.txt:4-5: only -std=c++17) and mixes f32 vectors with f64 wave
+// energy/time.  Everything below that feeds the image keeps that op order and
+// those types (this file is compiled with -ffp-contract=off); FMAs appear only
+// in the BVH slab test, which only has to be conservative.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rr_bvh.h"
+
+namespace rr {
+
+// ---------------------------------------------------------------- vec / quat
+struct V3 { float x, y, z; };
+struct Quat { float x, y, z, w; };
+
+__host__ __device__ inline V3 v_add(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+__host__ __device__ inline V3 v_sub(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+__host__ __device__ inline V3 v_neg(V3 a) { return { -a.x, -a.y, -a.z }; }
+__host__ __device__ inline V3 v_scale(V3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+__host__ __device__ inline float v_dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ inline V3 v_cross(V3 a, V3 b)
+{
+    return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+__host__ __device__ inline V3 v_normalize(V3 a)
+{
+    const float d = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return { a.x / d, a.y / d, a.z / d };
+}
+// rmagine Quaternion * Quaternion (Hamilton product), term order as in rmagine
+__host__ __device__ inline Quat q_mul(Quat a, Quat b)
+{
+    Quat r;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    return r;
+}
+__host__ __device__ inline Quat q_conj(Quat a) { return { -a.x, -a.y, -a.z, a.w }; }
+// rmagine Quaternion * Vector = (q (v,0) q^-1).xyz
+__host__ __device__ inline V3 q_rot(Quat q, V3 v)
+{
+    const Quat p = { v.x, v.y, v.z, 0.0f };
+    const Quat r = q_mul(q_mul(q, p), q_conj(q));
+    return { r.x, r.y, r.z };
+}
+
+// ------------------------------------------------------------ device params
+// Wave state, 48 B, three 16-B SoA streams (coalesced dwordx4 per lane):
+//   A = (orig.x, orig.y, orig.z, dir.x)   B = (dir.y, dir.z, material_id, -)
+//   C = (energy f64, time f64)            (radar_types.h:63-121; velocity and
+//   polarization never change on the CPU path -- SURVEY.md §2.3 #3 -- and are
+//   the constants 0.3 / 0.5 of RadarCPU.cpp:107-110)
+struct WaveBuf {
+    float4* A;
+    float4* B;
+    double2* C;
+};
+
+struct SigRec { int32_t cell; float strength; };
+
+struct Counters {
+    unsigned long long wave_passes, hits, signals, nodes, tris;
+    unsigned int overflow, pad;
+};
+
+struct Params {
+    // scene
+    const Node4* nodes;
+    const TriRec* tris;
+    // per-config tables
+    const float4* q_as;          // [n_angles] Tas.R (RadarCPU.cpp:202)
+    const float4* beams;         // [n_beam] xyz
+    const float4* materials;     // [n_materials] velocity, ambient, diffuse, specular
+    const int32_t* object_materials;
+    const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)
+    const float* noise_rnd;      // [n_angles] or null
+    // frame state
+    WaveBuf waves[2];            // [n_seg][2*cap] child slots, ping-pong by pass parity
+    uint32_t* idx[2];            // [n_seg][cap] live slot list
+    uint32_t* count[2];          // [n_seg]
+    uint8_t* cflag;              // [n_seg][2*cap] child alive flags (+ bit2 on slot 2j: hit)
+    SigRec* sigtmp;              // [n_seg][2*cap] per-wave signal slots (path, air)
+    float* hit_t;                // [n_seg][cap]
+    uint32_t* hit_tri;           // [n_seg][cap]
+    SigRec* sig;                 // [n_seg][sigcap] ordered signal list
+    uint32_t* sig_count;         // [n_seg]
+    uint32_t* spill;             // traversal stack spill [depth][threads]
+    Counters* counters;
+    uint8_t* cols_u8;            // [n_seg][n_cells]
+    float* cols_f32;             // optional
+    // scalars
+    Quat q_sm; V3 t_sm;
+    int az_begin, n_seg;
+    int n_beam, cap, sigcap;
+    int n_cells, n_angles, n_materials, n_objects, material_id_air;
+    int n_passes, record_multi_reflection, record_multi_path;
+    int signal_denoising, smear_w, smear_mode, ambient_noise, scroll;
+    float thr, range_max;
+    double resolution, multipath_threshold;
+    float energy_max_f;          // (float)energy_max  (cv convertTo alpha)
+    double signal_max;
+    double noise_at_0, noise_at_1, noise_e_max, noise_e_min, noise_e_loss;
+    int spill_stride, stack_lds;
+};
+
+}  // namespace rr

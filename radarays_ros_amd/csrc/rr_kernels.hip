@@ -1,0 +1,709 @@
+// rr_kernels.hip -- gfx950 kernels of the radar hot path.
+//
+// One frame = for each ray-cast pass p (RadarCPU.cpp:220):
+//     k_trace   nearest hit of every live wave against the BVH4   (RadarCPU.cpp:236)
+//     k_shade   move / material select / Fresnel split / BRDF     (RadarCPU.cpp:243-371)
+//     k_scan    ordered (stable) compaction of children + signals (RadarCPU.cpp:290,322,369,380)
+// then
+//     k_column  signals -> range-bin column, noise, scale, u8     (RadarCPU.cpp:402-542)
+// and (rr_assemble) a tiled transpose into the mono8 image.
+//
+// Ordering: the reference appends children and signals in wave order; float
+// accumulation into the slice depends on that order.  All compaction here is
+// prefix-sum based (no atomics), so the signal list of an azimuth is in exactly
+// the reference's order and the image does not depend on scheduling.
+#include "rr_device.h"
+
+namespace rr {
+
+// ---------------------------------------------------------------------------
+// common
+// ---------------------------------------------------------------------------
+__device__ inline Quat ld_quat(const float4* p) { const float4 v = *p; return { v.x, v.y, v.z, v.w }; }
+
+// Tam = Tsm * Tas (RadarCPU.cpp:201-206); Tas.t = 0.
+__device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t_am)
+{
+    const Quat q_as = ld_quat(P.q_as + (P.az_begin + seg));
+    q_am = q_mul(P.q_sm, q_as);
+    const V3 zero = { 0.0f, 0.0f, 0.0f };
+    t_am = v_add(q_rot(P.q_sm, zero), P.t_sm);
+}
+
+struct Hit { float t; uint32_t tri; uint32_t face; };
+
+// ---------------------------------------------------------------------------
+// BVH4 traversal, one ray per lane, LDS stack with global spill
+// ---------------------------------------------------------------------------
+template <bool STATS>
+__device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris,
+                               V3 o, V3 d, float range_max,
+                               uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gtid,
+                               unsigned& n_nodes, unsigned& n_tris)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t* my = lds_stack + lane;   // entry e at my[e*64]
+    // clamp tiny direction components so 1/d stays finite (slab test only)
+    const float eps = 1e-20f;
+    const float dx = fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x;
+    const float dy = fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y;
+    const float dz = fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z;
+    const float idx = 1.0f / dx, idy = 1.0f / dy, idz = 1.0f / dz;
+    const float oox = -o.x * idx, ooy = -o.y * idy, ooz = -o.z * idz;
+
+    Hit best; best.t = __builtin_inff(); best.tri = 0xFFFFFFFFu; best.face = 0xFFFFFFFFu;
+    float tcull = range_max * 1.0001f + 1e-3f;
+    int sp = 0;
+    uint32_t cur = 0;   // root
+
+    while (true) {
+        if (!(cur & kLeafFlag)) {
+            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+            const uint4 ch = *reinterpret_cast<const uint4*>(np + 6);
+            if (STATS) n_nodes++;
+            uint32_t key[4];
+#define RR_SLAB(i, LX, LY, LZ, HX, HY, HZ)                                                     \
+            {                                                                                  \
+                const float ax = __builtin_fmaf(LX, idx, oox), bx = __builtin_fmaf(HX, idx, oox); \
+                const float ay = __builtin_fmaf(LY, idy, ooy), by = __builtin_fmaf(HY, idy, ooy); \
+                const float az = __builtin_fmaf(LZ, idz, ooz), bz = __builtin_fmaf(HZ, idz, ooz); \
+                const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)); \
+                const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f; \
+                const bool h = (tmin <= tmax) && (tmin <= tcull);                              \
+                key[i] = h ? ((__float_as_uint(tmin) & ~3u) | (uint32_t)i) : (0x7F800000u | (uint32_t)i); \
+            }
+            RR_SLAB(0, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x)
+            RR_SLAB(1, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y)
+            RR_SLAB(2, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z)
+            RR_SLAB(3, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w)
+#undef RR_SLAB
+            // sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest first
+#define RR_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+            RR_CSWAP(0, 1) RR_CSWAP(2, 3) RR_CSWAP(0, 2) RR_CSWAP(1, 3) RR_CSWAP(1, 2)
+#undef RR_CSWAP
+#define RR_REF(k) (((k) & 3u) == 0u ? ch.x : ((k) & 3u) == 1u ? ch.y : ((k) & 3u) == 2u ? ch.z : ch.w)
+#define RR_PUSH(r) { if (sp < stack_lds) my[sp * 64] = (r); else spill[(size_t)(sp - stack_lds) * spill_stride + gtid] = (r); sp++; }
+            if (key[3] < 0x7F800000u) RR_PUSH(RR_REF(key[3]))
+            if (key[2] < 0x7F800000u) RR_PUSH(RR_REF(key[2]))
+            if (key[1] < 0x7F800000u) RR_PUSH(RR_REF(key[1]))
+            if (key[0] < 0x7F800000u) { cur = RR_REF(key[0]); continue; }
+#undef RR_REF
+        } else {
+            const uint32_t first = cur & 0x0FFFFFFFu;
+            const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const float4* tp = reinterpret_cast<const float4*>(tris + (first + i));
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (STATS) n_tris++;
+                // Moeller-Trumbore, f32, un-fused: bit-identical to the CPU oracle
+                const V3 v0 = { a.x, a.y, a.z }, e1 = { b.x, b.y, b.z }, e2 = { c.x, c.y, c.z };
+                const V3 pvec = v_cross(d, e2);
+                const float det = v_dot(e1, pvec);
+                if (det == 0.0f) continue;
+                const float inv = 1.0f / det;
+                const V3 tvec = v_sub(o, v0);
+                const float u = v_dot(tvec, pvec) * inv;
+                if (!(u >= 0.0f && u <= 1.0f)) continue;
+                const V3 qvec = v_cross(tvec, e1);
+                const float v = v_dot(d, qvec) * inv;
+                if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+                const float t = v_dot(e2, qvec) * inv;
+                if (!(t > 0.0f && t <= range_max)) continue;
+                const uint32_t face = __float_as_uint(a.w);
+                if (t < best.t || (t == best.t && face < best.face)) {
+                    best.t = t; best.tri = first + i; best.face = face;
+                    tcull = t * 1.0001f + 1e-3f;
+                }
+            }
+        }
+        // pop
+        if (sp == 0) break;
+        sp--;
+        cur = (sp < stack_lds) ? my[sp * 64] : spill[(size_t)(sp - stack_lds) * spill_stride + gtid];
+    }
+#undef RR_PUSH
+    return best;
+}
+
+// grid: (ceil(cap/64), n_seg), block 64, dynamic LDS = stack_lds*64*4
+template <bool FIRST, bool STATS>
+__global__ __launch_bounds__(64) void k_trace(const Params P, const int pass)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const int seg = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 64 + lane;
+    const int cur = pass & 1;
+    const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
+    if ((int)(blockIdx.x * 64) >= count) return;
+    const bool active = j < count;
+
+    V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
+    if (active) {
+        if (FIRST) {
+            const float4 b = P.beams[j];
+            dir = { b.x, b.y, b.z };
+        } else {
+            const uint32_t slot = P.idx[cur][(size_t)seg * P.cap + j];
+            const size_t w = (size_t)seg * 2 * P.cap + slot;
+            const float4 A = P.waves[cur].A[w], B = P.waves[cur].B[w];
+            orig = { A.x, A.y, A.z };
+            dir = { A.w, B.x, B.y };
+        }
+    }
+    Quat q_am; V3 t_am;
+    azimuth_frame(P, seg, q_am, t_am);
+    const V3 o_m = v_add(q_rot(q_am, orig), t_am);
+    const V3 d_m = q_rot(q_am, dir);
+
+    unsigned nn = 0, nt = 0;
+    Hit h; h.t = __builtin_inff(); h.tri = 0xFFFFFFFFu; h.face = 0xFFFFFFFFu;
+    if (active) {
+        const int gtid = (blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane;
+        h = traverse<STATS>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
+                            P.spill, P.spill_stride, gtid, nn, nt);
+        const size_t k = (size_t)seg * P.cap + j;
+        P.hit_t[k] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
+        P.hit_tri[k] = h.tri;
+    }
+    if (STATS) {
+        for (int off = 32; off > 0; off >>= 1) { nn += __shfl_down(nn, off); nt += __shfl_down(nt, off); }
+        if (lane == 0) {
+            atomicAdd(&P.counters->nodes, (unsigned long long)nn);
+            atomicAdd(&P.counters->tris, (unsigned long long)nt);
+        }
+    }
+}
+
+// generic rays (tests): one thread per ray
+__global__ __launch_bounds__(64) void k_debug_trace(const Params P, const float* origs, const float* dirs, int n,
+                                                    float* out_t, uint32_t* out_face)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = { origs[3 * i], origs[3 * i + 1], origs[3 * i + 2] };
+    const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
+    unsigned nn = 0, nt = 0;
+    const Hit h = traverse<false>(P.nodes, P.tris, o, d, P.range_max, lds_stack, P.stack_lds,
+                                  P.spill, P.spill_stride, i, nn, nt);
+    out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
+    out_face[i] = h.face;
+}
+
+// ---------------------------------------------------------------------------
+// per-hit radar math
+// ---------------------------------------------------------------------------
+// acos(float) in the reference is the C++ float overload (acosf): the angle is
+// an f32 value widened to f64 (this is what makes R_eff > 1 for v2 = 0, see
+// SURVEY.md §8c).  Computed as the f32 rounding of the f64 acos.
+__device__ inline float acosf_ref(float x) { return (float)acos((double)x); }
+
+// radar_algorithms.h:55-139 (only dir + energy of both results are used,
+// RadarCPU.cpp:285-286,364-365)
+__device__ inline void fresnel_split(V3 n, const V3 d, const double energy, const double v1, const double v2,
+                                     V3& rdir, double& renergy, V3& tdir, double& tenergy)
+{
+    const double polarization = 0.5;   // RadarCPU.cpp:108
+    const double n1 = v2, n2 = v1;     // radar_algorithms.h:62-63
+    const double incidence_angle = (double)acosf_ref(v_dot(v_neg(d), n));
+    rdir = v_add(d, v_scale(v_scale(n, 2.0f), v_dot(v_neg(n), d)));   // :73
+    tdir = { 0.0f, 0.0f, 0.0f };
+    if (n1 > 0.0) {
+        const double n21 = n2 / n1;
+        double angle_limit = 100.0;
+        if (fabs(n21) <= 1.0) angle_limit = asin(n21);
+        if (incidence_angle <= angle_limit) {
+            if (v_dot(n, d) > 0.0f) n = v_neg(n);   // :92
+            if (n2 > 0.0) {
+                const double n12 = n1 / n2;
+                const double c = cos(incidence_angle);
+                tdir = v_add(v_scale(d, (float)n12),
+                             v_scale(n, (float)(n12 * c - sqrt(1 - n12 * n12 * (1 - c * c)))));   // :100
+            }
+        }
+    }
+    const double refraction_angle = (double)acosf_ref(v_dot(tdir, v_neg(n)));   // :106
+    double rs, rp;
+    const double eps = 0.0001;
+    const double s = incidence_angle + refraction_angle;
+    if (s < eps) {
+        rs = (n1 - n2) / (n1 + n2);
+        rp = rs;
+    } else if (s > M_PI - eps) {
+        rs = 1.0; rp = 1.0;
+    } else {
+        const double df = incidence_angle - refraction_angle;
+        rs = -sin(df) / sin(s);
+        rp = tan(df) / tan(s);
+    }
+    const double Rs = rs * rs, Rp = rp * rp;
+    const double Reff = polarization * Rs + (1.0 - polarization) * Rp;
+    const double Teff = 1.0 - Reff;
+    renergy = Reff * energy;
+    tenergy = Teff * energy;
+}
+
+// radar_algorithms.h:168-187
+__device__ inline float back_reflection_shader(float incidence_angle, float energy,
+                                               float diffuse, float specular_fac, float specular_exp)
+{
+    const float IdotR = cosf(incidence_angle);
+    const float I_specular = powf(IdotR, specular_exp);
+    const float I_total = diffuse * 1.0f + specular_fac * I_specular;
+    return I_total * energy;
+}
+
+// RadarCPU.cpp:410-413: time -> range bin
+__device__ inline int signal_cell(double time, double resolution)
+{
+    const float half_time = (float)(time / 2.0);
+    const float signal_dist = (float)(0.3 * (double)half_time);
+    return (int)((double)signal_dist / resolution);
+}
+
+// grid: (ceil(cap/256), n_seg), block 256
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_shade(const Params P, const int pass)
+{
+    const int seg = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int cur = pass & 1, nxt = cur ^ 1;
+    const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
+    if (j >= count) return;
+    const bool last = (pass == P.n_passes - 1);
+
+    const size_t base2 = (size_t)seg * 2 * P.cap;
+    const size_t s0 = base2 + 2 * (size_t)j, s1 = s0 + 1;
+
+    V3 orig = { 0.0f, 0.0f, 0.0f }, dir;
+    double energy = 1.0, time = 0.0;   // RadarCPU.cpp:107,112
+    uint32_t mat = 0;                   // RadarCPU.cpp:111
+    if (FIRST) {
+        const float4 b = P.beams[j];
+        dir = { b.x, b.y, b.z };
+    } else {
+        const uint32_t slot = P.idx[cur][(size_t)seg * P.cap + j];
+        const size_t w = base2 + slot;
+        const float4 A = P.waves[cur].A[w], B = P.waves[cur].B[w];
+        const double2 C = P.waves[cur].C[w];
+        orig = { A.x, A.y, A.z };
+        dir = { A.w, B.x, B.y };
+        mat = __float_as_uint(B.z);
+        energy = C.x; time = C.y;
+    }
+
+    uint8_t f0 = 0, f1 = 0;
+    SigRec sg0 = { -1, 0.0f }, sg1 = { -1, 0.0f };
+
+    const float range = P.hit_t[(size_t)seg * P.cap + j];
+    if (range >= 0.0f)   // miss => the wave dies silently (RadarCPU.cpp:252-255)
+    {
+        f0 |= 4;
+        const uint32_t tri = P.hit_tri[(size_t)seg * P.cap + j];
+        const float4* tp = reinterpret_cast<const float4*>(P.tris + tri);
+        const float4 tb = tp[1], tc = tp[2];
+        const uint32_t obj_id = __float_as_uint(tb.w);
+        const V3 e1 = { tb.x, tb.y, tb.z }, e2 = { tc.x, tc.y, tc.z };
+
+        Quat q_am; V3 t_am;
+        azimuth_frame(P, seg, q_am, t_am);
+        // rmagine: geometric normal, normalised, rotated into the sensor frame,
+        // flipped to oppose the ray; RadarCPU.cpp:248 normalises once more
+        V3 nint = v_normalize(v_cross(e1, e2));
+        nint = q_rot(q_conj(q_am), nint);
+        if (v_dot(dir, nint) > 0.0f) nint = v_neg(nint);
+        const V3 normal = v_normalize(nint);
+
+        // incidence = wave.move(range)  (radar_types.h:108-120)
+        const V3 dir_in = dir;
+        orig = v_add(orig, v_scale(dir, range));
+        time += (double)range / 0.3;
+
+        // material select (RadarCPU.cpp:266-280)
+        bool ok = true;
+        uint32_t mat_refr;
+        if ((int)mat == P.material_id_air) {
+            if (obj_id >= (uint32_t)P.n_objects) { ok = false; mat_refr = 0; }
+            else mat_refr = (uint32_t)P.object_materials[obj_id];
+        } else {
+            mat_refr = (uint32_t)P.material_id_air;
+        }
+        if (ok && mat_refr >= (uint32_t)P.n_materials) ok = false;
+        if (!ok) {
+            atomicOr(&P.counters->overflow, 2u);
+        } else {
+            const float4 m = P.materials[mat_refr];
+            const float v_refraction = (mat != mat_refr) ? m.x : (float)0.3;
+
+            V3 rdir, tdir; double renergy, tenergy;
+            fresnel_split(normal, dir_in, energy, 0.3, (double)v_refraction, rdir, renergy, tdir, tenergy);
+
+            const float skip_dist = 0.001f;   // RadarCPU.cpp:374
+            if (renergy > (double)P.thr)      // :288
+            {
+                if (!last) {
+                    f0 |= 1;
+                    const V3 o2 = v_add(orig, v_scale(rdir, skip_dist));
+                    const double t2 = time + (double)skip_dist / 0.3;
+                    P.waves[nxt].A[s0] = make_float4(o2.x, o2.y, o2.z, rdir.x);
+                    P.waves[nxt].B[s0] = make_float4(rdir.y, rdir.z, __uint_as_float(mat), 0.0f);
+                    P.waves[nxt].C[s0] = make_double2(renergy, t2);
+                }
+                if ((int)mat == P.material_id_air)   // :302
+                {
+                    const float incidence_angle = acosf_ref(v_dot(v_neg(dir_in), normal));   // :308
+                    const float ret = back_reflection_shader(incidence_angle, (float)renergy, m.y, m.z, m.w);
+                    if (pass == 0 || P.record_multi_reflection) {   // :319
+                        const float time_back = (float)(time * 2.0);
+                        sg0.cell = signal_cell((double)time_back, P.resolution);
+                        sg0.strength = ret;
+                        if (sg0.cell < 0) sg0.cell = -1;
+                    }
+                    if (pass > 0 && P.record_multi_path) {   // :325-360
+                        const float dist = sqrtf(orig.x * orig.x + orig.y * orig.y + orig.z * orig.z);
+                        const V3 dsh = { orig.x / dist, orig.y / dist, orig.z / dist };
+                        const double time_to_sensor = (double)dist / 0.3;
+                        const double sensor_view_scalar = (double)v_dot(dir_in, dsh);
+                        const float ang = acosf_ref(v_dot(v_neg(rdir), dsh));
+                        if (sensor_view_scalar > P.multipath_threshold) {
+                            sg1.strength = back_reflection_shader(ang, (float)renergy, m.y, m.z, m.w);
+                            sg1.cell = signal_cell(time + time_to_sensor, P.resolution);
+                            if (sg1.cell < 0) sg1.cell = -1;
+                        }
+                    }
+                }
+            }
+            if (!last && tenergy > (double)P.thr)   // :367
+            {
+                f1 |= 1;
+                const V3 o2 = v_add(orig, v_scale(tdir, skip_dist));
+                const double t2 = time + (double)skip_dist / 0.3;
+                P.waves[nxt].A[s1] = make_float4(o2.x, o2.y, o2.z, tdir.x);
+                P.waves[nxt].B[s1] = make_float4(tdir.y, tdir.z, __uint_as_float(mat_refr), 0.0f);
+                P.waves[nxt].C[s1] = make_double2(tenergy, t2);
+            }
+        }
+    }
+    P.cflag[s0] = f0; P.cflag[s1] = f1;
+    P.sigtmp[s0] = sg0; P.sigtmp[s1] = sg1;
+}
+
+// ---------------------------------------------------------------------------
+// ordered compaction: children -> idx[nxt], signals -> sig list.  grid n_seg, block 256
+// ---------------------------------------------------------------------------
+__device__ inline int block_excl_scan(int v, int& total, int* lds /*[8]*/)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int x = v;
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) lds[wid] = x;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int w = 0; w < 4; w++) { const int s = lds[w]; if (w < wid) pre += s; tot += s; }
+    __syncthreads();
+    total = tot;
+    return pre + x - v;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
+{
+    __shared__ int lds[8];
+    const int seg = blockIdx.x;
+    const int cur = pass & 1, nxt = cur ^ 1;
+    const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
+    const int n_slots = 2 * count;
+    const bool last = (pass == P.n_passes - 1);
+    const size_t base2 = (size_t)seg * 2 * P.cap;
+
+    int n_child = 0;
+    int n_sig = FIRST ? 0 : (int)P.sig_count[seg];
+    const int sig_before = n_sig;
+    int n_hit = 0;
+    unsigned ovf = 0;
+    for (int b = 0; b < n_slots; b += 256) {
+        const int s = b + threadIdx.x;
+        uint8_t f = 0; SigRec sr = { -1, 0.0f };
+        if (s < n_slots) { f = P.cflag[base2 + s]; sr = P.sigtmp[base2 + s]; }
+        const int hit = (f >> 2) & 1;
+        int tot;
+        if (!last) {
+            const int c = f & 1;
+            const int pos = n_child + block_excl_scan(c, tot, lds);
+            if (c) { if (pos < P.cap) P.idx[nxt][(size_t)seg * P.cap + pos] = (uint32_t)s; else ovf = 1; }
+            n_child += tot;
+        }
+        const int g = sr.cell >= 0 ? 1 : 0;
+        const int spos = n_sig + block_excl_scan(g, tot, lds);
+        if (g) { if (spos < P.sigcap) P.sig[(size_t)seg * P.sigcap + spos] = sr; else ovf = 1; }
+        n_sig += tot;
+        block_excl_scan(hit, tot, lds);
+        n_hit += tot;
+    }
+    if (__syncthreads_or((int)ovf) && threadIdx.x == 0) atomicOr(&P.counters->overflow, 1u);
+    if (threadIdx.x == 0) {
+        P.count[nxt][seg] = (uint32_t)min(n_child, P.cap);
+        P.sig_count[seg] = (uint32_t)min(n_sig, P.sigcap);
+        atomicAdd(&P.counters->wave_passes, (unsigned long long)count);
+        atomicAdd(&P.counters->hits, (unsigned long long)n_hit);
+        atomicAdd(&P.counters->signals, (unsigned long long)(n_sig - sig_before));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Perlin noise (image_algorithms.h:14-106), f64, table in constant memory
+// ---------------------------------------------------------------------------
+__constant__ unsigned char c_perm[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30,
+    69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62,
+    94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136,
+    171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122,
+    60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161,
+    1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86,
+    164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126,
+    255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+    119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253,
+    19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193,
+    238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31,
+    181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93,
+    222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180
+};
+__device__ inline int perm(int i) { return c_perm[i & 255]; }
+__device__ inline double p_fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }
+__device__ inline double p_lerp(double t, double a, double b) { return a + t * (b - a); }
+__device__ inline double p_grad(int hash, double x, double y, double z)
+{
+    const int h = hash & 15;
+    const double u = h < 8 ? x : y;
+    const double v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
+    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+}
+__device__ inline double perlin_noise(double sx, double sy)
+{
+    const double sz = 0.0;
+    const int X = (int)floor(sx) & 255, Y = (int)floor(sy) & 255, Z = (int)floor(sz) & 255;
+    const double x = sx - floor(sx), y = sy - floor(sy), z = sz - floor(sz);
+    const double u = p_fade(x), v = p_fade(y), w = p_fade(z);
+    const int A = perm(X) + Y, AA = perm(A) + Z, AB = perm(A + 1) + Z;
+    const int B = perm(X + 1) + Y, BA = perm(B) + Z, BB = perm(B + 1) + Z;
+    return p_lerp(w,
+        p_lerp(v, p_lerp(u, p_grad(perm(AA), x, y, z), p_grad(perm(BA), x - 1, y, z)),
+                  p_lerp(u, p_grad(perm(AB), x, y - 1, z), p_grad(perm(BB), x - 1, y - 1, z))),
+        p_lerp(v, p_lerp(u, p_grad(perm(AA + 1), x, y, z - 1), p_grad(perm(BA + 1), x - 1, y, z - 1)),
+                  p_lerp(u, p_grad(perm(AB + 1), x, y - 1, z - 1), p_grad(perm(BB + 1), x - 1, y - 1, z - 1))));
+}
+
+// defined variate stream for ambient_noise == 1 (the reference draws from
+// std::random_device, RadarCPU.cpp:461-482: unreproducible by construction)
+__device__ inline float uniform01(uint32_t seed, uint32_t col, uint32_t i)
+{
+    unsigned long long z = ((unsigned long long)seed << 40) ^ ((unsigned long long)col << 20) ^ (unsigned long long)i;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// cv::saturate_cast<uchar>(float): cvRound (round-half-even); NaN / out of int range -> 0
+__device__ inline uint8_t saturate_u8(float x)
+{
+    if (!(x > -2147483648.0f && x < 2147483648.0f)) return 0;
+    const float r = __builtin_rintf(x);
+    return (uint8_t)(r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r));
+}
+
+// ---------------------------------------------------------------------------
+// signals -> slice -> column  (RadarCPU.cpp:402-542).  grid n_seg, block 256.
+// Each lane owns one range bin of a 64-bin tile in a register and replays the
+// azimuth's signals IN ORDER (f64 add, f32 store like `slice.at<float>() +=`),
+// so the column is bit-reproducible and equal to the sequential CPU loop.
+// ---------------------------------------------------------------------------
+constexpr int kSigChunk = 2048;
+
+__global__ __launch_bounds__(256) void k_column(const Params P)
+{
+    extern __shared__ float lds_col[];              // [n_cells] slice
+    __shared__ SigRec s_sig[kSigChunk];
+    __shared__ float s_w[256];
+    __shared__ unsigned long long s_tiles[2];
+    __shared__ float s_red[4];
+
+    const int seg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n_cells = P.n_cells;
+    const int S = (int)P.sig_count[seg];
+    const int W = P.signal_denoising > 0 ? P.smear_w : 1;
+    const int mode = P.signal_denoising > 0 ? P.smear_mode : 0;
+    const int n_tiles = (n_cells + 63) >> 6;
+
+    for (int i = tid; i < n_cells; i += 256) lds_col[i] = 0.0f;
+    if (tid < W && P.signal_denoising > 0) s_w[tid] = P.smear[tid];
+    __syncthreads();
+
+    for (int c0 = 0; c0 < S; c0 += kSigChunk) {
+        const int n = min(kSigChunk, S - c0);
+        if (tid < 2) s_tiles[tid] = 0ull;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const SigRec r = P.sig[(size_t)seg * P.sigcap + c0 + i];
+            s_sig[i] = r;
+            if (r.cell < n_cells) {   // RadarCPU.cpp:414
+                int lo = r.cell - mode, hi = r.cell - mode + W - 1;
+                lo = max(lo, 0); hi = min(hi, n_cells - 1);
+                for (int t = lo >> 6; t <= (hi >> 6); t++) atomicOr(&s_tiles[t >> 6], 1ull << (t & 63));
+            }
+        }
+        __syncthreads();
+        for (int t = wid; t < n_tiles; t += 4) {
+            if (!((s_tiles[t >> 6] >> (t & 63)) & 1ull)) continue;
+            const int g = t * 64 + lane;
+            const int tlo = t * 64, thi = tlo + 63;
+            float acc = (g < n_cells) ? lds_col[g] : 0.0f;
+            for (int i = 0; i < n; i++) {
+                const int cell = __builtin_amdgcn_readfirstlane(s_sig[i].cell);
+                if (cell >= n_cells) continue;
+                const int first = cell - mode;
+                if (first > thi || first + W - 1 < tlo) continue;
+                const float str = s_sig[i].strength;
+                const int vid = g - first;
+                if (P.signal_denoising > 0) {
+                    if (vid >= 0 && vid < W && g > 0 && g < n_cells)   // :424
+                        acc = (float)((double)acc + (double)str * (double)s_w[vid]);
+                } else {
+                    if (vid == 0 && g < n_cells) acc = fmaxf(acc, str);   // :439
+                }
+            }
+            if (g < n_cells) lds_col[g] = acc;
+        }
+        __syncthreads();
+    }
+
+    // max_val: all adds are >= 0, so the running max of RadarCPU.cpp:428-431 is the final max
+    float m = 0.0f;
+    for (int i = tid; i < n_cells; i += 256) m = fmaxf(m, lds_col[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+    if (lane == 0) s_red[wid] = m;
+    __syncthreads();
+    const float max_val = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+
+    const int angle_id = P.az_begin + seg;
+    const int col = (P.scroll + angle_id) % P.n_angles;   // :457 (placement is done by the assemble step)
+    const float final_scale = (float)(P.signal_max / (double)max_val);   // :533
+    const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[angle_id] : 0.0f;
+
+    for (int i = tid; i < n_cells; i += 256) {
+        float v = lds_col[i] * P.energy_max_f;   // :453
+        if (P.ambient_noise) {   // :459-528
+            const float signal = v;
+            double p = 0.0;
+            if (P.ambient_noise == 1) {
+                p = (double)uniform01((uint32_t)(int)rnd, (uint32_t)col, (uint32_t)i);
+            } else if (P.ambient_noise == 2) {
+                const double random_begin = (double)rnd;
+                const double p1 = perlin_noise(random_begin + (double)i * 0.05, (double)col * 0.05);
+                const double p2 = perlin_noise(random_begin + (double)i * 0.2, (double)col * 0.2);
+                p = 0.9 * p1 + 0.1 * p2;
+            }
+            const float signal_max = max_val;
+            const float signal_amp = signal_max - 0.0f;
+            const float signal_ = (float)(1.0 - (double)((signal - 0.0f) / signal_amp));
+            const float noise_at_0 = (float)((double)signal_amp * P.noise_at_0);
+            const float noise_at_1 = (float)((double)signal_amp * P.noise_at_1);
+            const float signal__ = (float)pow((double)signal_, 4.0);
+            const float noise_amp = (float)((double)(signal__ * noise_at_0) + (1.0 - (double)signal__) * (double)noise_at_1);
+            const float noise_energy_max = (float)((double)signal_max * P.noise_e_max);
+            const float noise_energy_min = (float)((double)signal_max * P.noise_e_min);
+            const float energy_loss = (float)P.noise_e_loss;
+            float y_noise = (float)((double)noise_amp * p);
+            const float x = (float)(((double)(float)i + 0.5) * P.resolution);
+            y_noise = y_noise + (noise_energy_max - noise_energy_min) * expf(-energy_loss * x) + noise_energy_min;
+            y_noise = fabsf(y_noise);
+            v = signal + y_noise;
+        }
+        v = v * final_scale;
+        P.cols_u8[(size_t)seg * n_cells + i] = saturate_u8(v);   // :542
+        if (P.cols_f32) P.cols_f32[(size_t)seg * n_cells + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// columns [n_angles][n_cells] -> image [n_cells][n_angles], col = (scroll + a) % n_angles
+// grid (ceil(n_cells/64), ceil(n_angles/64)), block 256 (64x4)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_assemble(const T* __restrict__ cols, T* __restrict__ img,
+                                                  int n_angles, int n_cells, int scroll)
+{
+    __shared__ T tile[64][65];
+    const int c0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int a = a0 + r, c = c0 + tx;
+        if (a < n_angles && c < n_cells) tile[r][tx] = cols[(size_t)a * n_cells + c];
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, a = a0 + tx;
+        if (a < n_angles && c < n_cells) {
+            const int col = (scroll + a) % n_angles;
+            img[(size_t)c * n_angles + col] = tile[tx][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers (called from rr_api.cpp through plain C++ prototypes)
+// ---------------------------------------------------------------------------
+void launch_trace(const Params& P, int pass, bool stats, hipStream_t s)
+{
+    const int cap_p = pass == 0 ? P.n_beam : P.cap;
+    dim3 grid((cap_p + 63) / 64, P.n_seg), block(64);
+    const size_t lds = (size_t)P.stack_lds * 64 * sizeof(uint32_t);
+    if (pass == 0) {
+        if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, s, P, pass);
+        else       hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, s, P, pass);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, s, P, pass);
+        else       hipLaunchKernelGGL((k_trace<false, false>), grid, block, lds, s, P, pass);
+    }
+}
+
+void launch_shade(const Params& P, int pass, hipStream_t s)
+{
+    const int cap_p = pass == 0 ? P.n_beam : P.cap;
+    dim3 grid((cap_p + 255) / 256, P.n_seg), block(256);
+    if (pass == 0) hipLaunchKernelGGL((k_shade<true>), grid, block, 0, s, P, pass);
+    else           hipLaunchKernelGGL((k_shade<false>), grid, block, 0, s, P, pass);
+}
+
+void launch_scan(const Params& P, int pass, hipStream_t s)
+{
+    dim3 grid(P.n_seg), block(256);
+    if (pass == 0) hipLaunchKernelGGL((k_scan<true>), grid, block, 0, s, P, pass);
+    else           hipLaunchKernelGGL((k_scan<false>), grid, block, 0, s, P, pass);
+}
+
+void launch_column(const Params& P, hipStream_t s)
+{
+    dim3 grid(P.n_seg), block(256);
+    hipLaunchKernelGGL(k_column, grid, block, (size_t)P.n_cells * sizeof(float), s, P);
+}
+
+void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s)
+{
+    dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64), block(256);
+    hipLaunchKernelGGL((k_assemble<uint8_t>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll);
+}
+
+void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
+                        float* out_t, uint32_t* out_face, hipStream_t s)
+{
+    dim3 grid((n + 63) / 64), block(64);
+    const size_t lds = (size_t)P.stack_lds * 64 * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_debug_trace, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
+}
+
+}  // namespace rr

@@ -1,0 +1,265 @@
+"""ctypes binding of libradarays_mi355.so (include/radarays_mi355.h).
+
+This is the ONLY compute path of the package: if the library is missing or no
+HIP device is usable, everything here raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libradarays_mi355.so")
+_LIB = None
+
+SYMBOLS = [
+    "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
+    "rr_set_mesh", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
+    "rr_set_noise_offsets", "rr_simulate", "rr_simulate_columns_device",
+    "rr_assemble_image_device", "rr_simulate_device", "rr_synchronize", "rr_get_stats",
+    "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
+    "rr_get_kernel_time",
+]
+
+
+class RRMaterial(C.Structure):
+    _fields_ = [("velocity", C.c_float), ("ambient", C.c_float),
+                ("diffuse", C.c_float), ("specular", C.c_float)]
+
+
+class RRConfig(C.Structure):
+    _fields_ = [
+        ("n_cells", C.c_int32), ("n_angles", C.c_int32), ("n_reflections", C.c_int32),
+        ("signal_denoising", C.c_int32),
+        ("signal_denoising_triangular_width", C.c_int32),
+        ("signal_denoising_gaussian_width", C.c_int32),
+        ("signal_denoising_mb_width", C.c_int32),
+        ("ambient_noise", C.c_int32), ("scroll_image", C.c_int32),
+        ("record_multi_reflection", C.c_int32), ("record_multi_path", C.c_int32),
+        ("max_waves_per_azimuth", C.c_int32),
+        ("resolution", C.c_double), ("energy_max", C.c_double), ("signal_max", C.c_double),
+        ("signal_denoising_triangular_mode", C.c_double),
+        ("signal_denoising_gaussian_mode", C.c_double),
+        ("signal_denoising_mb_mode", C.c_double),
+        ("ambient_noise_at_signal_0", C.c_double), ("ambient_noise_at_signal_1", C.c_double),
+        ("ambient_noise_energy_max", C.c_double), ("ambient_noise_energy_min", C.c_double),
+        ("ambient_noise_energy_loss", C.c_double), ("multipath_threshold", C.c_double),
+        ("wave_energy_threshold", C.c_float), ("theta_min", C.c_float),
+        ("theta_inc", C.c_float), ("range_max", C.c_float),
+    ]
+
+
+class RRStats(C.Structure):
+    _fields_ = [("wave_passes", C.c_uint64), ("hits", C.c_uint64), ("signals", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+                ("overflow", C.c_uint32), ("pad_", C.c_uint32)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the in-tree shared library."""
+    src = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src, f) for f in os.listdir(src)] + [os.path.join(_HERE, "..", "include", "radarays_mi355.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", src], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "radarays_ros_amd: %s is missing -- build it with __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        # share torch's HIP runtime when torch is in the process: both resolve the
+        # SONAME libamdhip64.so.7, the first one loaded wins
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rr_abi_version.restype = C.c_int
+    L.rr_default_config.argtypes = [C.POINTER(RRConfig)]
+    L.rr_create.restype = vp
+    L.rr_create.argtypes = [C.c_int]
+    L.rr_destroy.argtypes = [vp]
+    L.rr_last_error.restype = C.c_char_p
+    L.rr_last_error.argtypes = [vp]
+    L.rr_set_mesh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.rr_set_materials.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int32]
+    L.rr_set_config.argtypes = [vp, C.POINTER(RRConfig)]
+    L.rr_set_beam_samples.argtypes = [vp, vp, C.c_size_t]
+    L.rr_set_noise_offsets.argtypes = [vp, vp, C.c_size_t]
+    L.rr_simulate.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(RRStats)]
+    L.rr_simulate_columns_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.rr_assemble_image_device.argtypes = [vp, vp, vp, vp]
+    L.rr_simulate_device.argtypes = [vp, vp, vp, vp]
+    L.rr_synchronize.argtypes = [vp, vp]
+    L.rr_get_stats.argtypes = [vp, C.POINTER(RRStats)]
+    L.rr_set_stats_mode.argtypes = [vp, C.c_int]
+    L.rr_set_timing_mode.argtypes = [vp, C.c_int]
+    L.rr_get_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+    L.rr_debug_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.rr_get_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    for n in SYMBOLS:
+        f = getattr(L, n)
+        if f.restype is C.c_int and n not in ("rr_abi_version",):
+            pass
+    _LIB = L
+    return L
+
+
+def make_config(cfg, n_angles=400, max_waves_per_azimuth=0, wave_energy_threshold=0.001,
+                ray_range_max=1000.0):
+    """RadarModelConfig (params.py) -> rr_config."""
+    c = RRConfig()
+    lib().rr_default_config(C.byref(c))
+    c.n_cells = int(cfg.n_cells)
+    c.n_angles = int(n_angles)
+    c.n_reflections = int(cfg.n_reflections)
+    c.signal_denoising = int(cfg.signal_denoising)
+    c.signal_denoising_triangular_width = int(cfg.signal_denoising_triangular_width)
+    c.signal_denoising_gaussian_width = int(cfg.signal_denoising_gaussian_width)
+    c.signal_denoising_mb_width = int(cfg.signal_denoising_mb_width)
+    c.ambient_noise = int(cfg.ambient_noise)
+    c.scroll_image = int(cfg.scroll_image)
+    c.record_multi_reflection = int(bool(cfg.record_multi_reflection))
+    c.record_multi_path = int(bool(cfg.record_multi_path))
+    c.max_waves_per_azimuth = int(max_waves_per_azimuth)
+    for k in ("resolution", "energy_max", "signal_max", "signal_denoising_triangular_mode",
+              "signal_denoising_gaussian_mode", "signal_denoising_mb_mode",
+              "ambient_noise_at_signal_0", "ambient_noise_at_signal_1",
+              "ambient_noise_energy_max", "ambient_noise_energy_min",
+              "ambient_noise_energy_loss", "multipath_threshold"):
+        setattr(c, k, float(getattr(cfg, k)))
+    c.wave_energy_threshold = float(np.float32(wave_energy_threshold))
+    c.theta_min = 0.0
+    c.theta_inc = float(np.float32(-(2.0 * np.pi) / n_angles))   # Radar.cpp:27
+    c.range_max = float(ray_range_max)                            # radar_algorithms.cpp:158
+    return c
+
+
+class RRError(RuntimeError):
+    pass
+
+
+class Context:
+    """Owns one rr_ctx (one GPU)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        self._h = self._L.rr_create(int(device))
+        if not self._h:
+            raise RRError(self._L.rr_last_error(None).decode())
+        self.device = int(device)
+        self.cfg = None
+        self.n_angles = 400
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RRError("%s (rc=%d)" % (self._L.rr_last_error(self._h).decode(), rc))
+
+    def set_mesh(self, verts, faces, face_object_id=None):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
+        o = None if face_object_id is None else np.ascontiguousarray(face_object_id, np.uint32)
+        if o is not None and len(o) != len(f):
+            raise ValueError("face_object_id must have one entry per face")
+        self._ck(self._L.rr_set_mesh(self._h, v.ctypes.data, len(v), f.ctypes.data, len(f),
+                                     None if o is None else o.ctypes.data))
+
+    def set_materials(self, materials, object_materials, material_id_air=0):
+        m = (RRMaterial * len(materials))(*[RRMaterial(*[float(x) for x in (t.astuple() if hasattr(t, "astuple") else t)])
+                                            for t in materials])
+        om = np.ascontiguousarray(object_materials, np.int32)
+        self._ck(self._L.rr_set_materials(self._h, m, len(materials), om.ctypes.data, len(om), int(material_id_air)))
+
+    def set_config(self, cfg, n_angles=400, **kw):
+        self.cfg = cfg
+        self.n_angles = n_angles
+        self._rrcfg = make_config(cfg, n_angles, **kw)
+        self._ck(self._L.rr_set_config(self._h, C.byref(self._rrcfg)))
+
+    def set_beam_samples(self, dirs):
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        self._ck(self._L.rr_set_beam_samples(self._h, d.ctypes.data, len(d)))
+
+    def set_noise_offsets(self, rnd):
+        r = np.ascontiguousarray(rnd, np.float32)
+        self._ck(self._L.rr_set_noise_offsets(self._h, r.ctypes.data, len(r)))
+
+    def simulate(self, pose, az_begin=0, az_end=None, want_f32=False):
+        """Host-buffer path (rr_simulate). Returns (u8 [n_cells][n_angles], f32|None, stats)."""
+        p = np.ascontiguousarray(pose, np.float32)
+        assert p.shape == (7,)
+        if az_end is None:
+            az_end = self.n_angles
+        u8 = np.zeros((self.cfg.n_cells, self.n_angles), np.uint8)
+        f32 = np.zeros((self.cfg.n_cells, self.n_angles), np.float32) if want_f32 else None
+        st = RRStats()
+        self._ck(self._L.rr_simulate(self._h, p.ctypes.data, az_begin, az_end, u8.ctypes.data,
+                                     None if f32 is None else f32.ctypes.data, C.byref(st)))
+        return u8, f32, st.asdict()
+
+    def simulate_columns_device(self, pose, az_begin, az_end, d_cols_u8_ptr, d_cols_f32_ptr=None, stream=None):
+        p = np.ascontiguousarray(pose, np.float32)
+        self._ck(self._L.rr_simulate_columns_device(self._h, p.ctypes.data, az_begin, az_end,
+                                                    d_cols_u8_ptr, d_cols_f32_ptr, stream))
+
+    def assemble_image_device(self, d_cols_u8_ptr, d_img_ptr, stream=None):
+        self._ck(self._L.rr_assemble_image_device(self._h, d_cols_u8_ptr, d_img_ptr, stream))
+
+    def simulate_device(self, pose, d_img_ptr, stream=None):
+        p = np.ascontiguousarray(pose, np.float32)
+        self._ck(self._L.rr_simulate_device(self._h, p.ctypes.data, d_img_ptr, stream))
+
+    def synchronize(self, stream=None):
+        self._ck(self._L.rr_synchronize(self._h, stream))
+
+    def stats(self):
+        st = RRStats()
+        self._ck(self._L.rr_get_stats(self._h, C.byref(st)))
+        return st.asdict()
+
+    def set_stats_mode(self, on):
+        self._ck(self._L.rr_set_stats_mode(self._h, int(bool(on))))
+
+    def set_timing_mode(self, on):
+        self._ck(self._L.rr_set_timing_mode(self._h, int(bool(on))))
+
+    def kernel_time(self, name, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        self._ck(self._L.rr_get_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def bvh_info(self):
+        a, b, d, s = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        self._ck(self._L.rr_get_bvh_info(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(s)))
+        return {"n_nodes": a.value, "n_tris": b.value, "depth": d.value, "stack_need": s.value}
+
+    def debug_trace(self, origs, dirs):
+        o = np.ascontiguousarray(origs, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        t = np.zeros(len(o), np.float32)
+        f = np.zeros(len(o), np.uint32)
+        self._ck(self._L.rr_debug_trace(self._h, o.ctypes.data, d.ctypes.data, len(o), t.ctypes.data, f.ctypes.data))
+        return t, f

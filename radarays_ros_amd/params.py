@@ -1,0 +1,113 @@
+"""Parameter surface of the reference kept 1:1.
+
+RadarModelConfig mirrors cfg/RadarModel.cfg:11-85 (dynamic_reconfigure fields,
+same names, defaults and ranges); RadarMaterial / RadarModel / RadarParams mirror
+msg/RadarMaterial.msg, msg/RadarModel.msg, msg/RadarParams.msg; default_params()
+mirrors include/radarays_ros/ros_helper.h (beam 8 deg, 200 samples, 2 reflections).
+"""
+from dataclasses import dataclass, field, asdict
+from typing import List
+import math
+
+
+@dataclass
+class RadarMaterial:            # msg/RadarMaterial.msg:1-4
+    velocity: float = 0.3
+    ambient: float = 1.0
+    diffuse: float = 0.0
+    specular: float = 1.0
+
+    def astuple(self):
+        return (self.velocity, self.ambient, self.diffuse, self.specular)
+
+
+@dataclass
+class RadarModel:               # msg/RadarModel.msg:1-3
+    beam_width: float = 8.0 * math.pi / 180.0   # radians (Radar.cpp:213)
+    n_samples: int = 200
+    n_reflections: int = 2
+
+
+@dataclass
+class RadarParams:              # msg/RadarParams.msg
+    materials: List[RadarMaterial] = field(default_factory=list)
+    model: RadarModel = field(default_factory=RadarModel)
+
+
+def default_params() -> RadarParams:
+    """include/radarays_ros/ros_helper.h:21-35."""
+    return RadarParams(materials=[], model=RadarModel())
+
+
+@dataclass
+class RadarModelConfig:         # cfg/RadarModel.cfg
+    z_offset: float = 0.0
+    range_min: float = 0.0
+    range_max: float = 600.0
+    beam_width: float = 8.0                    # degrees
+    resolution: float = 0.0438
+    n_cells: int = 3424
+    n_samples: int = 10
+    beam_sample_dist: int = 2                  # 0 D1, 1 D2, 2 D3 normal, 3 D4
+    beam_sample_dist_normal_p_in_cone: float = 0.8
+    n_reflections: int = 4
+    energy_min: float = 0.0
+    energy_max: float = 0.5
+    signal_max: float = 120.0
+    signal_denoising: int = 1                  # 0 none 1 triangular 2 gaussian 3 maxwell_boltzmann
+    signal_denoising_triangular_width: int = 50
+    signal_denoising_triangular_mode: float = 0.35
+    signal_denoising_gaussian_width: int = 50
+    signal_denoising_gaussian_mode: float = 0.5
+    signal_denoising_mb_width: int = 50
+    signal_denoising_mb_mode: float = 0.4
+    ambient_noise: int = 2                     # 0 none 1 uniform 2 perlin
+    ambient_noise_at_signal_0: float = 0.3
+    ambient_noise_at_signal_1: float = 0.03
+    ambient_noise_energy_max: float = 0.5
+    ambient_noise_energy_min: float = 0.1
+    ambient_noise_energy_loss: float = 0.05
+    ambient_noise_uniform_max: float = 0.15    # unused on the CPU path
+    ambient_noise_perlin_scale_low: float = 0.05
+    ambient_noise_perlin_scale_high: float = 0.2
+    ambient_noise_perlin_p_low: float = 0.9
+    scroll_image: int = 0
+    multipath_threshold: float = 0.5
+    record_multi_reflection: bool = True
+    record_multi_path: bool = False
+    include_motion: bool = True
+
+    def copy(self, **kw):
+        d = asdict(self)
+        d.update(kw)
+        return RadarModelConfig(**d)
+
+
+def kaist_preset(**kw) -> RadarModelConfig:
+    """cfg/mulran_kaist_dyncfg.yaml (the paper preset)."""
+    c = RadarModelConfig(
+        ambient_noise=2, ambient_noise_at_signal_0=0.1, ambient_noise_at_signal_1=0.03,
+        ambient_noise_energy_loss=0.05, ambient_noise_energy_max=0.1, ambient_noise_energy_min=0.05,
+        ambient_noise_uniform_max=0.15, beam_sample_dist=2, beam_sample_dist_normal_p_in_cone=0.8,
+        beam_width=10.0, energy_max=0.72, energy_min=0.0, include_motion=False,
+        multipath_threshold=0.5, n_cells=3424, n_reflections=4, n_samples=50,
+        range_max=600.0, range_min=0.0, record_multi_path=False, record_multi_reflection=True,
+        resolution=0.0595238, scroll_image=0, signal_denoising=1,
+        signal_denoising_gaussian_mode=0.5, signal_denoising_gaussian_width=50,
+        signal_denoising_mb_mode=0.4, signal_denoising_mb_width=50,
+        signal_denoising_triangular_mode=0.35, signal_denoising_triangular_width=35,
+        signal_max=110.0, z_offset=0.0)
+    return c.copy(**kw)
+
+
+def kaist_materials() -> List[RadarMaterial]:
+    """config/mulran_kaist02.yaml:8-20 (air, wall stone)."""
+    return [RadarMaterial(0.3, 1.0, 0.0, 1.0), RadarMaterial(0.0, 1.0, 0.0, 3000.0)]
+
+
+# one penetrable material so that Snell/Fresnel splitting
+# actually occurs (the KAIST table alone never refracts: v = 0)
+PENETRABLE = RadarMaterial(0.1, 0.6, 0.3, 30.0)
+
+N_ANGLES = 400                       # Radar.cpp:29
+WAVE_ENERGY_THRESHOLD = 0.001        # Radar.cpp:24

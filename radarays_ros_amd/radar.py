@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference's backend interface for this path.
+
+Reference seam (C++):   class Radar { virtual sensor_msgs::ImagePtr simulate(ros::Time) = 0; }
+                        include/radarays_ros/Radar.hpp:34-105, src/radarays_ros/Radar.cpp
+Backends there:         RadarCPU (Embree), RadarGPU (OptiX) -- chosen in radar_simulator.cpp:118-176.
+`RadarHIP` is the third backend: same member names / same argument meaning /
+same error behaviour (simulate() returns None when no transform is known, like
+the null ImagePtr of RadarCPU.cpp:129-133), on top of libradarays_mi355.so.
+ROS itself is absent here: TF lookup is replaced by updateTsm(pose) and the
+returned message is a plain `Image` object with sensor_msgs/Image's fields.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import beams, native
+from .params import (N_ANGLES, WAVE_ENERGY_THRESHOLD, RadarModelConfig, RadarParams,
+                     default_params)
+
+
+@dataclass
+class Header:
+    stamp: float = 0.0
+    frame_id: str = ""
+
+
+@dataclass
+class Image:
+    """sensor_msgs/Image as RadarCPU.cpp:555-561 fills it."""
+    header: Header = field(default_factory=Header)
+    height: int = 0
+    width: int = 0
+    encoding: str = "mono8"
+    is_bigendian: int = 0
+    step: int = 0
+    data: np.ndarray = None     # [height][width] uint8
+
+
+class RadarHIP:
+    def __init__(self, verts, faces, face_object_id=None, map_frame="map", sensor_frame="sensor",
+                 device=0, beam_seed=42):
+        self.m_map_frame = map_frame
+        self.m_sensor_frame = sensor_frame
+        self.m_params: RadarParams = default_params()          # Radar.cpp:22
+        self.m_material_id_air = 0                             # Radar.cpp:23
+        self.m_wave_energy_threshold = WAVE_ENERGY_THRESHOLD   # Radar.cpp:24
+        self.m_resample = True                                 # Radar.cpp:25
+        self.m_object_materials = []
+        self.m_cfg = RadarModelConfig()
+        self.m_waves_start = None
+        self.Tsm_last = None
+        self._beam_seed = beam_seed
+        self._noise_seed = 7
+        self._ctx = native.Context(device)
+        self._ctx.set_mesh(verts, faces, face_object_id)
+        self._dirty_cfg = True
+        self._dirty_mat = True
+        self.updateDynCfg(self.m_cfg)
+
+    # -- Radar.cpp:220-226
+    def loadParams(self, materials, object_materials, material_id_air=0):
+        self.m_params.materials = list(materials)
+        self.m_object_materials = list(object_materials)
+        self.m_material_id_air = int(material_id_air)
+        self._dirty_mat = True
+
+    def getParams(self):
+        return self.m_params
+
+    def setParams(self, params: RadarParams):
+        self.m_params = params
+        self._dirty_mat = True
+        self._dirty_cfg = True
+
+    # -- Radar.cpp:188-218
+    def updateDynCfg(self, config: RadarModelConfig, level=0):
+        old = self.m_cfg
+        if (config.beam_sample_dist != old.beam_sample_dist
+                or abs(config.beam_width - old.beam_width) > 0.001
+                or config.n_samples != old.n_samples
+                or abs(config.beam_sample_dist_normal_p_in_cone - old.beam_sample_dist_normal_p_in_cone) > 0.001):
+            self.m_resample = True
+        self.m_params.model.beam_width = config.beam_width * np.pi / 180.0
+        self.m_params.model.n_samples = config.n_samples
+        self.m_params.model.n_reflections = config.n_reflections
+        self.m_cfg = config.copy()
+        self._dirty_cfg = True
+
+    # -- Radar.cpp:80-132 (TF lookup replaced by an explicit pose)
+    def updateTsm(self, pose_qxyzw_t=None):
+        if pose_qxyzw_t is not None:
+            p = np.asarray(pose_qxyzw_t, np.float32)
+            if p.shape != (7,) or not np.all(np.isfinite(p)):
+                return False
+            self.Tsm_last = p
+        return self.Tsm_last is not None
+
+    def setBeamSamples(self, dirs):
+        """Inject m_waves_start (tests use the committed fixture)."""
+        self.m_waves_start = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        self.m_resample = False
+        self._ctx.set_beam_samples(self.m_waves_start)
+
+    def setNoiseOffsets(self, rnd):
+        self._ctx.set_noise_offsets(rnd)
+
+    def _push(self):
+        if self._dirty_cfg:
+            cfg = self.m_cfg.copy(n_reflections=self.m_params.model.n_reflections)
+            self._ctx.set_config(cfg, N_ANGLES, wave_energy_threshold=self.m_wave_energy_threshold)
+            self._dirty_cfg = False
+        if self._dirty_mat:
+            self._ctx.set_materials(self.m_params.materials, self.m_object_materials, self.m_material_id_air)
+            self._dirty_mat = False
+        if self.m_resample:     # RadarCPU.cpp:136-145
+            self.m_waves_start = beams.sample_cone_local(
+                self.m_cfg.beam_width, self.m_params.model.n_samples, self.m_cfg.beam_sample_dist,
+                self.m_cfg.beam_sample_dist_normal_p_in_cone, seed=self._beam_seed)
+            self._ctx.set_beam_samples(self.m_waves_start)
+            self.m_resample = False
+
+    # -- the seam: Radar.hpp:64 / RadarCPU.cpp:30-564
+    def simulate(self, stamp=0.0, want_f32=False):
+        if not self.updateTsm():
+            print("Couldn't get Transform between sensor and map. Skipping...")   # RadarCPU.cpp:131
+            return None
+        self._push()
+        u8, f32, stats = self._ctx.simulate(self.Tsm_last, 0, N_ANGLES, want_f32=want_f32)
+        msg = Image(header=Header(stamp=stamp, frame_id=self.m_sensor_frame),
+                    height=u8.shape[0], width=u8.shape[1], encoding="mono8", step=u8.shape[1], data=u8)
+        self.last_f32 = f32
+        self.last_stats = stats
+        return msg
+
+    @property
+    def context(self):
+        return self._ctx

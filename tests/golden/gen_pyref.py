@@ -1,0 +1,52 @@
+"""Generates tests/golden/pyref_*.json by IMPORTING the reference's own python
+scripts from /root/reference (only possible in the dev container; the vectors,
+not the scripts, are committed).
+
+    MPLBACKEND=Agg python tests/golden/gen_pyref.py
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True   # never write into /root/reference
+os.environ.setdefault("MPLBACKEND", "Agg")
+REF = "/root/reference/scripts"
+sys.path.insert(0, os.path.join(REF, "reflections"))
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import fresnel as ref_fresnel  # noqa: E402   scripts/reflections/fresnel.py
+import snell_multi as ref_snell  # noqa: E402  scripts/reflections/snell_multi.py
+import maxwell_boltzmann as ref_mb  # noqa: E402  scripts/maxwell_boltzmann.py
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+cases = []
+for theta_deg in [0.0, 5.0, 10.0, 20.0, 30.0, 45.0, 60.0, 75.0, 85.0, 89.0]:
+    for v2 in [0.03, 0.05, 0.1, 0.15, 0.2, 0.25, 0.3, 0.45]:
+        th = np.radians(theta_deg)
+        d = np.array([np.cos(th), np.sin(th)])
+        n = np.array([-1.0, 0.0])
+        v1 = 0.3
+        # reference convention (radar_algorithms.h:62-63): n1 := v2, n2 := v1
+        refl, _ = ref_fresnel.fresnel_reflect_dir(n, d, v2, v1)
+        refr, _ = ref_fresnel.fresnel_refract_dir(n, d, v2, v1)
+        cases.append({
+            "theta_deg": theta_deg, "v1": v1, "v2": v2,
+            "incident_angle": float(ref_fresnel.incident_angle(n, d)),
+            "reflect_dir": [float(x) for x in refl],
+            "refract_dir": [float(x) for x in refr],
+            "snell_multi_reflect": [float(x) for x in ref_snell.snell_reflect_dir(n, d)],
+        })
+json.dump({"_provenance": "scripts/reflections/fresnel.py:25-57, snell_multi.py:11-20 imported from /root/reference",
+           "cases": cases}, open(os.path.join(HERE, "pyref_snell.json"), "w"), indent=1)
+
+mb = []
+for width, mode in [(50, 20), (35, 12), (100, 40), (10, 3)]:
+    x = np.arange(width, dtype=np.float64)
+    y = ref_mb.maxwell_boltzmann_pdf(x, a=ref_mb.maxwell_boltzmann_a_from_mode(mode))
+    y = y / y.sum()
+    mb.append({"width": width, "mode": mode, "normalized": [float(v) for v in y]})
+json.dump({"_provenance": "scripts/maxwell_boltzmann.py:6-10 imported from /root/reference", "cases": mb},
+          open(os.path.join(HERE, "pyref_mb.json"), "w"), indent=1)
+print("wrote pyref_snell.json (%d cases), pyref_mb.json (%d cases)" % (len(cases), len(mb)))

@@ -1,0 +1,90 @@
+"""The C-ABI library loads and exports every symbol include/radarays_mi355.h
+declares; struct layouts of the ctypes binding match the header.  No compute."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "radarays_mi355.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built_and_exports_every_declared_symbol(native_lib):
+    native_lib.build()
+    L = C.CDLL(native_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "missing symbol %s" % n
+    assert sorted(native_lib.SYMBOLS) == names
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(HEADER).read()
+    assert "torch" not in src.lower() and "at::" not in src and "c10" not in src
+
+
+def test_struct_layouts_match_header(native_lib, tmp_path):
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "radarays_mi355.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(rr_config), sizeof(rr_material),'
+                    ' sizeof(rr_stats), offsetof(rr_config, resolution), offsetof(rr_config, wave_energy_threshold),'
+                    ' offsetof(rr_config, range_max));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    cfg, mat, st, off_res, off_thr, off_rm = map(int, out)
+    assert C.sizeof(native_lib.RRConfig) == cfg
+    assert C.sizeof(native_lib.RRMaterial) == mat == 16
+    assert C.sizeof(native_lib.RRStats) == st
+    assert native_lib.RRConfig.resolution.offset == off_res
+    assert native_lib.RRConfig.wave_energy_threshold.offset == off_thr
+    assert native_lib.RRConfig.range_max.offset == off_rm
+
+
+def test_default_config_matches_reference_cfg(native_lib):
+    """rr_default_config == cfg/RadarModel.cfg defaults (params.RadarModelConfig())."""
+    from radarays_ros_amd import params
+    c = native_lib.RRConfig()
+    native_lib.lib().rr_default_config(C.byref(c))
+    d = params.RadarModelConfig()
+    for k in ("n_cells", "n_reflections", "signal_denoising", "signal_denoising_triangular_width",
+              "signal_denoising_gaussian_width", "signal_denoising_mb_width", "ambient_noise", "scroll_image",
+              "resolution", "energy_max", "signal_max", "signal_denoising_triangular_mode",
+              "signal_denoising_gaussian_mode", "signal_denoising_mb_mode", "ambient_noise_at_signal_0",
+              "ambient_noise_at_signal_1", "ambient_noise_energy_max", "ambient_noise_energy_min",
+              "ambient_noise_energy_loss", "multipath_threshold"):
+        assert getattr(c, k) == getattr(d, k), k
+    assert c.n_angles == 400 and abs(c.theta_inc + 2 * 3.141592653589793 / 400) < 1e-8
+    assert abs(c.wave_energy_threshold - 0.001) < 1e-9 and c.range_max == 1000.0
+    assert c.record_multi_reflection == 1 and c.record_multi_path == 0
+    assert native_lib.lib().rr_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(native_lib, monkeypatch, tmp_path):
+    monkeypatch.setattr(native_lib, "_LIB", None)
+    monkeypatch.setattr(native_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native_lib.lib()
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped package must not import/link/execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "radarays_ros_amd")
+    bad = re.compile(r"import\s+oracle|from\s+oracle|oracle/|libradarays_oracle|\borc_[a-z]")
+    n = 0
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")) or f == "Makefile":
+                n += 1
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert not bad.search(txt), f
+    assert n >= 10
