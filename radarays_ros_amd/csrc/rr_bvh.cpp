@@ -163,10 +163,11 @@ struct Collapser {
             cand[pick] = l; cand[nc++] = l + 1;
         }
         Node4 nd;
-        const float inf = std::numeric_limits<float>::infinity();
+        // empty slot: a degenerate box at +3e38 -- the slab test then yields t = +-huge
+        // on every axis and can never pass (inverted +-inf boxes would: min/max reorder them)
         for (int i = 0; i < 4; i++) {
-            nd.lo_x[i] = nd.lo_y[i] = nd.lo_z[i] = inf;
-            nd.hi_x[i] = nd.hi_y[i] = nd.hi_z[i] = -inf;
+            nd.lo_x[i] = nd.lo_y[i] = nd.lo_z[i] = kEmptyCoord;
+            nd.hi_x[i] = nd.hi_y[i] = nd.hi_z[i] = kEmptyCoord;
             nd.child[i] = kEmptyRef; nd.meta[i] = 0;
         }
         nd.meta[0] = (uint32_t)nc;
@@ -213,11 +214,10 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
     for (size_t i = 0; i < 3 * nv; i++) {
         if (!std::isfinite(verts[i])) { err = "rr_set_mesh: non-finite vertex"; return false; }
     }
-    const float inf = std::numeric_limits<float>::infinity();
     if (nf == 0) {
         Node4 nd;
         for (int i = 0; i < 4; i++) {
-            nd.lo_x[i] = nd.lo_y[i] = nd.lo_z[i] = inf; nd.hi_x[i] = nd.hi_y[i] = nd.hi_z[i] = -inf;
+            nd.lo_x[i] = nd.lo_y[i] = nd.lo_z[i] = kEmptyCoord; nd.hi_x[i] = nd.hi_y[i] = nd.hi_z[i] = kEmptyCoord;
             nd.child[i] = kEmptyRef; nd.meta[i] = 0;
         }
         out.nodes.push_back(nd);

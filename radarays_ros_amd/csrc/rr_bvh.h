@@ -16,10 +16,11 @@ namespace rr {
 // child reference encoding
 //   inner : node index (< 0x80000000)
 //   leaf  : 0x80000000 | (count-1) << 28 | first_triangle   (count 1..8, first < 2^28)
-//   empty : box = (+inf, -inf), ref = kEmptyRef
+//   empty : box = degenerate point at kEmptyCoord (never hit), ref = kEmptyRef
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0x7FFFFFFFu;
 constexpr uint32_t kMaxLeafTris = 4;
+constexpr float kEmptyCoord = 3.0e38f;
 
 struct alignas(16) Node4 {
     float lo_x[4], lo_y[4], lo_z[4];

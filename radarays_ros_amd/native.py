@@ -213,8 +213,9 @@ class Context:
         assert p.shape == (7,)
         if az_end is None:
             az_end = self.n_angles
-        u8 = np.zeros((self.cfg.n_cells, self.n_angles), np.uint8)
-        f32 = np.zeros((self.cfg.n_cells, self.n_angles), np.float32) if want_f32 else None
+        n_cells = self.cfg.n_cells if self.cfg is not None else 1   # unconfigured: the library reports it
+        u8 = np.zeros((n_cells, self.n_angles), np.uint8)
+        f32 = np.zeros((n_cells, self.n_angles), np.float32) if want_f32 else None
         st = RRStats()
         self._ck(self._L.rr_simulate(self._h, p.ctypes.data, az_begin, az_end, u8.ctypes.data,
                                      None if f32 is None else f32.ctypes.data, C.byref(st)))
