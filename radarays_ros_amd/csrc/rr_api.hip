@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -89,6 +90,8 @@ struct rr_ctx {
     DevBuf<SigRec> d_sigtmp, d_sig;
     DevBuf<float> d_hit_t, d_cols_f32;
     DevBuf<Counters> d_counters;
+    DevBuf<SegStats> d_seg_stats;
+    int last_n_seg = 0, last_n_passes = 0;
     int spill_stride = 0, stack_lds = 1;
 
     bool stats_mode = false, timing = false;
@@ -239,6 +242,7 @@ int ensure_frame_buffers(rr_ctx* c, int n_seg, bool want_f32)
     RR_HIP(c, c->d_sig.ensure(S * sigcap));
     RR_HIP(c, c->d_sig_count.ensure(S));
     RR_HIP(c, c->d_counters.ensure(1));
+    RR_HIP(c, c->d_seg_stats.ensure(S * (size_t)std::max(1, g.n_reflections)));
     RR_HIP(c, c->d_cols_u8.ensure(S * g.n_cells));
     if (want_f32) RR_HIP(c, c->d_cols_f32.ensure(S * g.n_cells));
     // traversal stack: LDS part + spill
@@ -266,7 +270,7 @@ void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_
         P.idx[k] = c->d_idx[k].p; P.count[k] = c->d_count[k].p;
     }
     P.cflag = c->d_cflag.p; P.sigtmp = c->d_sigtmp.p; P.hit_t = c->d_hit_t.p; P.hit_tri = c->d_hit_tri.p;
-    P.sig = c->d_sig.p; P.sig_count = c->d_sig_count.p; P.spill = c->d_spill.p; P.counters = c->d_counters.p;
+    P.sig = c->d_sig.p; P.sig_count = c->d_sig_count.p; P.spill = c->d_spill.p; P.counters = c->d_counters.p; P.seg_stats = c->d_seg_stats.p;
     P.cols_u8 = d_cols_u8; P.cols_f32 = d_cols_f32;
     P.q_sm = { pose[0], pose[1], pose[2], pose[3] };
     P.t_sm = { pose[4], pose[5], pose[6] };
@@ -287,6 +291,8 @@ void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_
     P.noise_e_max = g.ambient_noise_energy_max; P.noise_e_min = g.ambient_noise_energy_min;
     P.noise_e_loss = g.ambient_noise_energy_loss;
     P.spill_stride = c->spill_stride; P.stack_lds = c->stack_lds;
+    static const int dbg = getenv("RR_DEBUG") ? atoi(getenv("RR_DEBUG")) : 0;
+    P.debug = dbg;
 }
 
 struct TimedScope {
@@ -326,12 +332,12 @@ int run_frame(rr_ctx* c, const float pose[7], int az_begin, int az_end,
     }
     Params P;
     fill_params(c, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
-    RR_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), s));
-    RR_HIP(c, hipMemsetAsync(c->d_sig_count.p, 0, sizeof(uint32_t) * (size_t)n_seg, s));
+    if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), s));
+    c->last_n_seg = n_seg; c->last_n_passes = g.n_reflections;
     for (int pass = 0; pass < g.n_reflections; pass++) {
         { TimedScope t(c, s, "trace"); launch_trace(P, pass, c->stats_mode, s); }
         { TimedScope t(c, s, "shade"); launch_shade(P, pass, s); }
-        { TimedScope t(c, s, "scan"); launch_scan(P, pass, s); }
+        if (pass < g.n_reflections - 1) { TimedScope t(c, s, "scan"); launch_scan(P, pass, s); }
     }
     { TimedScope t(c, s, "column"); launch_column(P, s); }
     RR_HIP(c, hipGetLastError());
@@ -396,7 +402,7 @@ void rr_destroy(rr_ctx* c)
     c->d_objmat.release(); c->d_smear.release(); c->d_noise.release();
     for (int k = 0; k < 2; k++) { c->d_wA[k].release(); c->d_wB[k].release(); c->d_wC[k].release(); c->d_idx[k].release(); c->d_count[k].release(); }
     c->d_hit_tri.release(); c->d_sig_count.release(); c->d_spill.release(); c->d_cflag.release(); c->d_cols_u8.release();
-    c->d_sigtmp.release(); c->d_sig.release(); c->d_hit_t.release(); c->d_cols_f32.release(); c->d_counters.release();
+    c->d_sigtmp.release(); c->d_sig.release(); c->d_hit_t.release(); c->d_cols_f32.release(); c->d_counters.release(); c->d_seg_stats.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -530,8 +536,13 @@ int rr_get_stats(rr_ctx* c, rr_stats* st)
     if (!c->d_counters.p) return 0;
     Counters h;
     RR_HIP(c, hipMemcpy(&h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
-    st->wave_passes = h.wave_passes; st->hits = h.hits; st->signals = h.signals;
     st->nodes_visited = h.nodes; st->tris_tested = h.tris; st->overflow = h.overflow;
+    const size_t n = (size_t)c->last_n_seg * (size_t)c->last_n_passes;
+    if (n && c->d_seg_stats.p) {
+        std::vector<SegStats> ss(n);
+        RR_HIP(c, hipMemcpy(ss.data(), c->d_seg_stats.p, n * sizeof(SegStats), hipMemcpyDeviceToHost));
+        for (const SegStats& x : ss) { st->wave_passes += x.wave_passes; st->hits += x.hits; st->signals += x.signals; }
+    }
     return 0;
 }
 

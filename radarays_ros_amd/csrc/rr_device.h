@@ -65,9 +65,13 @@ struct WaveBuf {
 struct SigRec { int32_t cell; float strength; };
 
 struct Counters {
-    unsigned long long wave_passes, hits, signals, nodes, tris;
-    unsigned int overflow, pad;
+    unsigned long long nodes, tris;   // stats mode only (atomics)
+    unsigned int overflow, pad;       // error bits, set on rare error paths
 };
+
+// per (pass, azimuth) counters, written once by the kernel that finishes the pass
+// (no atomics in the frame path: ~10 ns each, they serialise at the L2)
+struct SegStats { uint32_t wave_passes, hits, signals, pad; };
 
 struct Params {
     // scene
@@ -92,6 +96,7 @@ struct Params {
     uint32_t* sig_count;         // [n_seg]
     uint32_t* spill;             // traversal stack spill [depth][threads]
     Counters* counters;
+    SegStats* seg_stats;         // [n_passes][n_seg]
     uint8_t* cols_u8;            // [n_seg][n_cells]
     float* cols_f32;             // optional
     // scalars
@@ -107,6 +112,7 @@ struct Params {
     double signal_max;
     double noise_at_0, noise_at_1, noise_e_max, noise_e_min, noise_e_loss;
     int spill_stride, stack_lds;
+    int debug;                   // RR_DEBUG env bits (perf experiments only)
 };
 
 }  // namespace rr

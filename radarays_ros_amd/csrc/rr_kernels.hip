@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64) void k_trace(const Params P, const int pass)
     const int j = blockIdx.x * 64 + lane;
     const int cur = pass & 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
+    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) P.counters->overflow = 0;   // error bits of this frame
     if ((int)(blockIdx.x * 64) >= count) return;
     const bool active = j < count;
 
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
     const int cur = pass & 1, nxt = cur ^ 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
     const int n_slots = 2 * count;
-    const bool last = (pass == P.n_passes - 1);
+    const bool last = false;   // the last pass is consumed directly by k_column
     const size_t base2 = (size_t)seg * 2 * P.cap;
 
     int n_child = 0;
@@ -446,9 +447,9 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
     if (threadIdx.x == 0) {
         P.count[nxt][seg] = (uint32_t)min(n_child, P.cap);
         P.sig_count[seg] = (uint32_t)min(n_sig, P.sigcap);
-        atomicAdd(&P.counters->wave_passes, (unsigned long long)count);
-        atomicAdd(&P.counters->hits, (unsigned long long)n_hit);
-        atomicAdd(&P.counters->signals, (unsigned long long)(n_sig - sig_before));
+        SegStats st; st.wave_passes = (uint32_t)count; st.hits = (uint32_t)n_hit;
+        st.signals = (uint32_t)(n_sig - sig_before); st.pad = 0;
+        P.seg_stats[(size_t)pass * P.n_seg + seg] = st;
     }
 }
 
@@ -522,79 +523,126 @@ __device__ inline uint8_t saturate_u8(float x)
 // so the column is bit-reproducible and equal to the sequential CPU loop.
 // ---------------------------------------------------------------------------
 constexpr int kSigChunk = 2048;
+constexpr int kColThreads = 512;
+constexpr int kColWaves = kColThreads / 64;
 
-__global__ __launch_bounds__(256) void k_column(const Params P)
+__global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 {
     extern __shared__ float lds_col[];              // [n_cells] slice
     __shared__ SigRec s_sig[kSigChunk];
     __shared__ float s_w[256];
     __shared__ unsigned long long s_tiles[2];
-    __shared__ float s_red[4];
+    __shared__ float s_red[kColWaves];
 
     const int seg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n_cells = P.n_cells;
-    const int S = (int)P.sig_count[seg];
     const int W = P.signal_denoising > 0 ? P.smear_w : 1;
     const int mode = P.signal_denoising > 0 ? P.smear_mode : 0;
     const int n_tiles = (n_cells + 63) >> 6;
 
-    for (int i = tid; i < n_cells; i += 256) lds_col[i] = 0.0f;
+    // signal stream of this azimuth, in the reference's order: the compacted list of
+    // passes 0..P-2 followed by the per-wave slots of the last pass (invalid = cell < 0)
+    const int n_list = (P.n_passes > 1) ? (int)P.sig_count[seg] : 0;
+    int count_last = 0;
+    if (P.n_passes == 1) count_last = P.n_beam;
+    else if (P.n_passes > 1) count_last = (int)P.count[(P.n_passes - 1) & 1][seg];
+    const int n_slots = 2 * count_last;
+    const int S = n_list + n_slots;
+    const size_t base2 = (size_t)seg * 2 * P.cap;
+
+    for (int i = tid; i < n_cells; i += kColThreads) lds_col[i] = 0.0f;
     if (tid < W && P.signal_denoising > 0) s_w[tid] = P.smear[tid];
     __syncthreads();
 
+    int n_valid_last = 0, n_hit_last = 0;
     for (int c0 = 0; c0 < S; c0 += kSigChunk) {
         const int n = min(kSigChunk, S - c0);
         if (tid < 2) s_tiles[tid] = 0ull;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const SigRec r = P.sig[(size_t)seg * P.sigcap + c0 + i];
+        for (int i = tid; i < n; i += kColThreads) {
+            if (P.debug & 4) break;
+            const int v = c0 + i;
+            SigRec r;
+            if (v < n_list) r = P.sig[(size_t)seg * P.sigcap + v];
+            else {
+                r = P.sigtmp[base2 + (v - n_list)];
+                n_valid_last += r.cell >= 0;
+                n_hit_last += (P.cflag[base2 + (v - n_list)] >> 2) & 1;
+            }
+            if (r.cell < 0 || r.cell >= n_cells) r.cell = 0x40000000;   // RadarCPU.cpp:414 / no signal
             s_sig[i] = r;
-            if (r.cell < n_cells) {   // RadarCPU.cpp:414
+            if (r.cell < n_cells) {
                 int lo = r.cell - mode, hi = r.cell - mode + W - 1;
                 lo = max(lo, 0); hi = min(hi, n_cells - 1);
                 for (int t = lo >> 6; t <= (hi >> 6); t++) atomicOr(&s_tiles[t >> 6], 1ull << (t & 63));
             }
         }
         __syncthreads();
-        for (int t = wid; t < n_tiles; t += 4) {
+        for (int t = wid; t < n_tiles; t += kColWaves) {
+            if (P.debug & 1) break;
             if (!((s_tiles[t >> 6] >> (t & 63)) & 1ull)) continue;
             const int g = t * 64 + lane;
             const int tlo = t * 64, thi = tlo + 63;
+            const bool g_ok = g > 0 && g < n_cells;      // RadarCPU.cpp:424 (bin 0 is never written)
             float acc = (g < n_cells) ? lds_col[g] : 0.0f;
-            for (int i = 0; i < n; i++) {
-                const int cell = __builtin_amdgcn_readfirstlane(s_sig[i].cell);
-                if (cell >= n_cells) continue;
-                const int first = cell - mode;
-                if (first > thi || first + W - 1 < tlo) continue;
-                const float str = s_sig[i].strength;
-                const int vid = g - first;
-                if (P.signal_denoising > 0) {
-                    if (vid >= 0 && vid < W && g > 0 && g < n_cells)   // :424
-                        acc = (float)((double)acc + (double)str * (double)s_w[vid]);
-                } else {
-                    if (vid == 0 && g < n_cells) acc = fmaxf(acc, str);   // :439
+            // scan 64 signals per step; replay the overlapping ones in order
+            for (int b0 = 0; b0 < n; b0 += 64) {
+                const int i = b0 + lane;
+                SigRec r; r.cell = 0x40000000; r.strength = 0.0f;
+                if (i < n) r = s_sig[i];
+                const int first = r.cell - mode;
+                const bool ov = !(first > thi || first + W - 1 < tlo);
+                unsigned long long m = __ballot(ov);
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int f_b = __builtin_amdgcn_readlane(first, b);
+                    const float s_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), b));
+                    const int vid = g - f_b;
+                    if (P.signal_denoising > 0) {
+                        if (vid >= 0 && vid < W && g_ok)
+                            acc = (float)((double)acc + (double)s_b * (double)s_w[vid]);   // :426
+                    } else {
+                        if (vid == 0 && g < n_cells) acc = fmaxf(acc, s_b);               // :439
+                    }
                 }
             }
             if (g < n_cells) lds_col[g] = acc;
         }
         __syncthreads();
     }
+    // counters of the last pass (earlier passes are written by k_scan)
+    {
+        __shared__ int s_cnt[2];
+        if (tid < 2) s_cnt[tid] = 0;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { n_valid_last += __shfl_down(n_valid_last, off); n_hit_last += __shfl_down(n_hit_last, off); }
+        if (lane == 0) { atomicAdd(&s_cnt[0], n_valid_last); atomicAdd(&s_cnt[1], n_hit_last); }
+        __syncthreads();
+        if (tid == 0 && P.n_passes > 0) {
+            SegStats st; st.wave_passes = (uint32_t)count_last; st.hits = (uint32_t)s_cnt[1];
+            st.signals = (uint32_t)s_cnt[0]; st.pad = 0;
+            P.seg_stats[(size_t)(P.n_passes - 1) * P.n_seg + seg] = st;
+        }
+    }
 
     // max_val: all adds are >= 0, so the running max of RadarCPU.cpp:428-431 is the final max
     float m = 0.0f;
-    for (int i = tid; i < n_cells; i += 256) m = fmaxf(m, lds_col[i]);
+    for (int i = tid; i < n_cells; i += kColThreads) m = fmaxf(m, lds_col[i]);
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
     if (lane == 0) s_red[wid] = m;
     __syncthreads();
-    const float max_val = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float max_val = 0.0f;
+    for (int k = 0; k < kColWaves; k++) max_val = fmaxf(max_val, s_red[k]);
 
     const int angle_id = P.az_begin + seg;
     const int col = (P.scroll + angle_id) % P.n_angles;   // :457 (placement is done by the assemble step)
     const float final_scale = (float)(P.signal_max / (double)max_val);   // :533
     const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[angle_id] : 0.0f;
 
-    for (int i = tid; i < n_cells; i += 256) {
+    for (int i = tid; i < n_cells; i += kColThreads) {
+        if (P.debug & 2) break;
         float v = lds_col[i] * P.energy_max_f;   // :453
         if (P.ambient_noise) {   // :459-528
             const float signal = v;
@@ -688,7 +736,7 @@ void launch_scan(const Params& P, int pass, hipStream_t s)
 
 void launch_column(const Params& P, hipStream_t s)
 {
-    dim3 grid(P.n_seg), block(256);
+    dim3 grid(P.n_seg), block(kColThreads);
     hipLaunchKernelGGL(k_column, grid, block, (size_t)P.n_cells * sizeof(float), s, P);
 }
 
