@@ -246,7 +246,7 @@ int ensure_frame_buffers(rr_ctx* c, int n_seg, bool want_f32)
     RR_HIP(c, c->d_cols_u8.ensure(S * g.n_cells));
     if (want_f32) RR_HIP(c, c->d_cols_f32.ensure(S * g.n_cells));
     // traversal stack: LDS part + spill
-    c->stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 24));
+    c->stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 64));   // 64 B of LDS per entry per wave
     const int spill_depth = (int)c->stack_need - c->stack_lds;
     const size_t threads = S * (size_t)((cap + 63) / 64) * 64;
     c->spill_stride = (int)threads;
@@ -621,7 +621,7 @@ int rr_debug_trace(rr_ctx* c, const float* origs, const float* dirs, size_t n, f
     if (!origs || !dirs || !out_t || !out_face) return fail(c, -3, "rr_debug_trace: null pointer");
     RR_HIP(c, hipSetDevice(c->device));
     const size_t chunk = 1u << 16;
-    const int stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 24));
+    const int stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 64));
     const int spill_depth = (int)c->stack_need - stack_lds;
     DevBuf<float> d_o, d_d, d_t; DevBuf<uint32_t> d_f, d_spill;
     RR_HIP(c, d_o.ensure(3 * chunk)); RR_HIP(c, d_d.ensure(3 * chunk)); RR_HIP(c, d_t.ensure(chunk));

@@ -166,8 +166,7 @@ struct Collapser {
         // empty slot: a degenerate box at +3e38 -- the slab test then yields t = +-huge
         // on every axis and can never pass (inverted +-inf boxes would: min/max reorder them)
         for (int i = 0; i < 4; i++) {
-            nd.lo_x[i] = nd.lo_y[i] = nd.lo_z[i] = kEmptyCoord;
-            nd.hi_x[i] = nd.hi_y[i] = nd.hi_z[i] = kEmptyCoord;
+            for (int k = 0; k < 6; k++) nd.box[i][k] = kEmptyCoord;
             nd.child[i] = kEmptyRef; nd.meta[i] = 0;
         }
         nd.meta[0] = (uint32_t)nc;
@@ -175,8 +174,7 @@ struct Collapser {
         uint32_t inner_self[4];
         for (int i = 0; i < nc; i++) {
             const Node2& c = n2[cand[i]];
-            nd.lo_x[i] = c.box.lo[0] - inflate; nd.lo_y[i] = c.box.lo[1] - inflate; nd.lo_z[i] = c.box.lo[2] - inflate;
-            nd.hi_x[i] = c.box.hi[0] + inflate; nd.hi_y[i] = c.box.hi[1] + inflate; nd.hi_z[i] = c.box.hi[2] + inflate;
+            for (int k = 0; k < 3; k++) { nd.box[i][k] = c.box.lo[k] - inflate; nd.box[i][3 + k] = c.box.hi[k] + inflate; }
             if (c.count) {
                 nd.child[i] = emit_leaf(c);
                 sah += (double)c.box.half_area() * c.count;
@@ -217,7 +215,7 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
     if (nf == 0) {
         Node4 nd;
         for (int i = 0; i < 4; i++) {
-            nd.lo_x[i] = nd.lo_y[i] = nd.lo_z[i] = kEmptyCoord; nd.hi_x[i] = nd.hi_y[i] = nd.hi_z[i] = kEmptyCoord;
+            for (int k = 0; k < 6; k++) nd.box[i][k] = kEmptyCoord;
             nd.child[i] = kEmptyRef; nd.meta[i] = 0;
         }
         out.nodes.push_back(nd);

@@ -22,9 +22,11 @@ constexpr uint32_t kEmptyRef = 0x7FFFFFFFu;
 constexpr uint32_t kMaxLeafTris = 4;
 constexpr float kEmptyCoord = 3.0e38f;
 
+// Child boxes are AoS (24 B each): the traversal kernel puts ONE RAY ON A QUAD of
+// lanes, lane q tests child q, so lane q fetches box[q] with three 8-byte loads and
+// all four lanes fetch child[] with one 16-byte load.
 struct alignas(16) Node4 {
-    float lo_x[4], lo_y[4], lo_z[4];
-    float hi_x[4], hi_y[4], hi_z[4];
+    float box[4][6];    // lo.xyz, hi.xyz
     uint32_t child[4];
     uint32_t meta[4];   // meta[0] = number of used children; rest reserved
 };

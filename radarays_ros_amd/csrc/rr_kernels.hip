@@ -33,16 +33,39 @@ __device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t
 struct Hit { float t; uint32_t tri; uint32_t face; };
 
 // ---------------------------------------------------------------------------
-// BVH4 traversal, one ray per lane, LDS stack with global spill
+// BVH4 traversal: ONE RAY PER QUAD of lanes (16 rays per wave64).
+//   inner node : lane q slab-tests child q; the four keys are exchanged with DPP
+//                quad_perm broadcasts (no LDS), every lane sorts them identically
+//   leaf       : lane q intersects triangle q (<= 4 per leaf); nearest by a DPP
+//                xor-butterfly on (t, face)
+// Control state (cur, sp, best) is replicated in the four lanes, so a quad never
+// diverges; the stack lives in LDS (one entry per ray, written by lane 0 of the
+// quad) and spills to global memory beyond `stack_lds` entries.
 // ---------------------------------------------------------------------------
+constexpr int kRaysPerWave = 16;
+constexpr int kTraceThreads = 256;                       // 64 rays per workgroup
+constexpr int kRaysPerBlock = kTraceThreads / 4;
+
+#define RR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true)
+#define RR_DPP_F(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xF, 0xF, true))
+// quad_perm encodings: broadcast lane k -> k*0x55; xor 1 -> 0xB1; xor 2 -> 0x4E
+#define RR_QBCAST0 0x00
+#define RR_QBCAST1 0x55
+#define RR_QBCAST2 0xAA
+#define RR_QBCAST3 0xFF
+#define RR_QXOR1 0xB1
+#define RR_QXOR2 0x4E
+
 template <bool STATS>
 __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris,
                                V3 o, V3 d, float range_max,
-                               uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gtid,
+                               uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gray,
                                unsigned& n_nodes, unsigned& n_tris)
 {
-    const int lane = threadIdx.x & 63;
-    uint32_t* my = lds_stack + lane;   // entry e at my[e*64]
+    const int q = threadIdx.x & 3;
+    const int wave = threadIdx.x >> 6;
+    const int rw = (threadIdx.x & 63) >> 2;                         // ray within the wave
+    uint32_t* my = lds_stack + (size_t)wave * stack_lds * kRaysPerWave + rw;   // entry e at my[e*16]
     // clamp tiny direction components so 1/d stays finite (slab test only)
     const float eps = 1e-20f;
     const float dx = fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x;
@@ -56,88 +79,93 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     int sp = 0;
     uint32_t cur = 0;   // root
 
+#define RR_PUSH(r) { if (q == 0) { if (sp < stack_lds) my[sp * kRaysPerWave] = (r); else spill[(size_t)(sp - stack_lds) * spill_stride + gray] = (r); } sp++; }
     while (true) {
         if (!(cur & kLeafFlag)) {
-            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-            const uint4 ch = *reinterpret_cast<const uint4*>(np + 6);
-            if (STATS) n_nodes++;
-            uint32_t key[4];
-#define RR_SLAB(i, LX, LY, LZ, HX, HY, HZ)                                                     \
-            {                                                                                  \
-                const float ax = __builtin_fmaf(LX, idx, oox), bx = __builtin_fmaf(HX, idx, oox); \
-                const float ay = __builtin_fmaf(LY, idy, ooy), by = __builtin_fmaf(HY, idy, ooy); \
-                const float az = __builtin_fmaf(LZ, idz, ooz), bz = __builtin_fmaf(HZ, idz, ooz); \
-                const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f)); \
-                const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f; \
-                const bool h = (tmin <= tmax) && (tmin <= tcull);                              \
-                key[i] = h ? ((__float_as_uint(tmin) & ~3u) | (uint32_t)i) : (0x7F800000u | (uint32_t)i); \
-            }
-            RR_SLAB(0, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x)
-            RR_SLAB(1, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y)
-            RR_SLAB(2, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z)
-            RR_SLAB(3, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w)
-#undef RR_SLAB
-            // sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest first
-#define RR_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
-            RR_CSWAP(0, 1) RR_CSWAP(2, 3) RR_CSWAP(0, 2) RR_CSWAP(1, 3) RR_CSWAP(1, 2)
+            const char* np = reinterpret_cast<const char*>(nodes + cur);
+            const float2* bp = reinterpret_cast<const float2*>(np + 24 * q);
+            const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];          // lo.x lo.y | lo.z hi.x | hi.y hi.z
+            const uint4 ch = *reinterpret_cast<const uint4*>(np + 96);
+            if (STATS) n_nodes += (q == 0);
+            const float ax = __builtin_fmaf(b0.x, idx, oox), bx = __builtin_fmaf(b1.y, idx, oox);
+            const float ay = __builtin_fmaf(b0.y, idy, ooy), by = __builtin_fmaf(b2.x, idy, ooy);
+            const float az = __builtin_fmaf(b1.x, idz, ooz), bz = __builtin_fmaf(b2.y, idz, ooz);
+            const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
+            const bool h = (tmin <= tmax) && (tmin <= tcull);
+            const uint32_t mykey = h ? ((__float_as_uint(tmin) & ~3u) | (uint32_t)q) : (0x7F800000u | (uint32_t)q);
+            uint32_t k0 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST0), k1 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST1);
+            uint32_t k2 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST2), k3 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST3);
+            // sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest first; identical in all 4 lanes
+#define RR_CSWAP(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
+            RR_CSWAP(k0, k1) RR_CSWAP(k2, k3) RR_CSWAP(k0, k2) RR_CSWAP(k1, k3) RR_CSWAP(k1, k2)
 #undef RR_CSWAP
 #define RR_REF(k) (((k) & 3u) == 0u ? ch.x : ((k) & 3u) == 1u ? ch.y : ((k) & 3u) == 2u ? ch.z : ch.w)
-#define RR_PUSH(r) { if (sp < stack_lds) my[sp * 64] = (r); else spill[(size_t)(sp - stack_lds) * spill_stride + gtid] = (r); sp++; }
-            if (key[3] < 0x7F800000u) RR_PUSH(RR_REF(key[3]))
-            if (key[2] < 0x7F800000u) RR_PUSH(RR_REF(key[2]))
-            if (key[1] < 0x7F800000u) RR_PUSH(RR_REF(key[1]))
-            if (key[0] < 0x7F800000u) { cur = RR_REF(key[0]); continue; }
+            if (k3 < 0x7F800000u) RR_PUSH(RR_REF(k3))
+            if (k2 < 0x7F800000u) RR_PUSH(RR_REF(k2))
+            if (k1 < 0x7F800000u) RR_PUSH(RR_REF(k1))
+            if (k0 < 0x7F800000u) { cur = RR_REF(k0); continue; }
 #undef RR_REF
         } else {
             const uint32_t first = cur & 0x0FFFFFFFu;
             const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; i++) {
-                const float4* tp = reinterpret_cast<const float4*>(tris + (first + i));
+            float t = __builtin_inff();
+            uint32_t face = 0xFFFFFFFFu, tri = 0xFFFFFFFFu;
+            if ((uint32_t)q < cnt) {
+                const float4* tp = reinterpret_cast<const float4*>(tris + (first + q));
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 if (STATS) n_tris++;
-                // Moeller-Trumbore, f32, un-fused: bit-identical to the CPU oracle
+                // Moeller-Trumbore, f32, un-fused: bit-identical to the CPU restatement
                 const V3 v0 = { a.x, a.y, a.z }, e1 = { b.x, b.y, b.z }, e2 = { c.x, c.y, c.z };
                 const V3 pvec = v_cross(d, e2);
                 const float det = v_dot(e1, pvec);
-                if (det == 0.0f) continue;
                 const float inv = 1.0f / det;
                 const V3 tvec = v_sub(o, v0);
                 const float u = v_dot(tvec, pvec) * inv;
-                if (!(u >= 0.0f && u <= 1.0f)) continue;
                 const V3 qvec = v_cross(tvec, e1);
                 const float v = v_dot(d, qvec) * inv;
-                if (!(v >= 0.0f && u + v <= 1.0f)) continue;
-                const float t = v_dot(e2, qvec) * inv;
-                if (!(t > 0.0f && t <= range_max)) continue;
-                const uint32_t face = __float_as_uint(a.w);
-                if (t < best.t || (t == best.t && face < best.face)) {
-                    best.t = t; best.tri = first + i; best.face = face;
-                    tcull = t * 1.0001f + 1e-3f;
-                }
+                const float tt = v_dot(e2, qvec) * inv;
+                const bool ok = (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
+                                (tt > 0.0f && tt <= range_max);
+                if (ok) { t = tt; face = __float_as_uint(a.w); tri = first + q; }
+            }
+            // quad-wide nearest (t, then lower face index)
+            {
+                float t2 = RR_DPP_F(t, RR_QXOR1);
+                uint32_t f2 = (uint32_t)RR_DPP_I(face, RR_QXOR1), r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR1);
+                bool take = (t2 < t) || (t2 == t && f2 < face);
+                t = take ? t2 : t; face = take ? f2 : face; tri = take ? r2 : tri;
+                t2 = RR_DPP_F(t, RR_QXOR2);
+                f2 = (uint32_t)RR_DPP_I(face, RR_QXOR2); r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR2);
+                take = (t2 < t) || (t2 == t && f2 < face);
+                t = take ? t2 : t; face = take ? f2 : face; tri = take ? r2 : tri;
+            }
+            if (t < best.t || (t == best.t && face < best.face)) {
+                best.t = t; best.tri = tri; best.face = face;
+                tcull = t * 1.0001f + 1e-3f;
             }
         }
         // pop
         if (sp == 0) break;
         sp--;
-        cur = (sp < stack_lds) ? my[sp * 64] : spill[(size_t)(sp - stack_lds) * spill_stride + gtid];
+        cur = (sp < stack_lds) ? my[sp * kRaysPerWave] : spill[(size_t)(sp - stack_lds) * spill_stride + gray];
     }
 #undef RR_PUSH
     return best;
 }
 
-// grid: (ceil(cap/64), n_seg), block 64, dynamic LDS = stack_lds*64*4
+// grid: (ceil(cap/64), n_seg), block 256 (= 64 rays), dynamic LDS = 4 waves * stack_lds * 16 * 4
 template <bool FIRST, bool STATS>
-__global__ __launch_bounds__(64) void k_trace(const Params P, const int pass)
+__global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
 {
     extern __shared__ uint32_t lds_stack[];
     const int seg = blockIdx.y;
-    const int lane = threadIdx.x;
-    const int j = blockIdx.x * 64 + lane;
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int j = blockIdx.x * kRaysPerBlock + r;
     const int cur = pass & 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
-    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) P.counters->overflow = 0;   // error bits of this frame
-    if ((int)(blockIdx.x * 64) >= count) return;
+    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
+    if ((int)(blockIdx.x * kRaysPerBlock) >= count) return;
     const bool active = j < count;
 
     V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
@@ -159,38 +187,41 @@ __global__ __launch_bounds__(64) void k_trace(const Params P, const int pass)
     const V3 d_m = q_rot(q_am, dir);
 
     unsigned nn = 0, nt = 0;
-    Hit h; h.t = __builtin_inff(); h.tri = 0xFFFFFFFFu; h.face = 0xFFFFFFFFu;
     if (active) {
-        const int gtid = (blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane;
-        h = traverse<STATS>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
-                            P.spill, P.spill_stride, gtid, nn, nt);
-        const size_t k = (size_t)seg * P.cap + j;
-        P.hit_t[k] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
-        P.hit_tri[k] = h.tri;
+        const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
+        const Hit h = traverse<STATS>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
+                                      P.spill, P.spill_stride, gray, nn, nt);
+        if (q == 0) {
+            const size_t k = (size_t)seg * P.cap + j;
+            P.hit_t[k] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
+            P.hit_tri[k] = h.tri;
+        }
     }
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) { nn += __shfl_down(nn, off); nt += __shfl_down(nt, off); }
-        if (lane == 0) {
+        if ((threadIdx.x & 63) == 0) {
             atomicAdd(&P.counters->nodes, (unsigned long long)nn);
             atomicAdd(&P.counters->tris, (unsigned long long)nt);
         }
     }
 }
 
-// generic rays (tests): one thread per ray
-__global__ __launch_bounds__(64) void k_debug_trace(const Params P, const float* origs, const float* dirs, int n,
-                                                    float* out_t, uint32_t* out_face)
+// generic rays (tests): one quad per ray
+__global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, const float* origs, const float* dirs, int n,
+                                                               float* out_t, uint32_t* out_face)
 {
     extern __shared__ uint32_t lds_stack[];
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.x * kRaysPerBlock + (threadIdx.x >> 2);
     if (i >= n) return;
     const V3 o = { origs[3 * i], origs[3 * i + 1], origs[3 * i + 2] };
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
     const Hit h = traverse<false>(P.nodes, P.tris, o, d, P.range_max, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
-    out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
-    out_face[i] = h.face;
+    if ((threadIdx.x & 3) == 0) {
+        out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
+        out_face[i] = h.face;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -708,8 +739,8 @@ __global__ __launch_bounds__(256) void k_assemble(const T* __restrict__ cols, T*
 void launch_trace(const Params& P, int pass, bool stats, hipStream_t s)
 {
     const int cap_p = pass == 0 ? P.n_beam : P.cap;
-    dim3 grid((cap_p + 63) / 64, P.n_seg), block(64);
-    const size_t lds = (size_t)P.stack_lds * 64 * sizeof(uint32_t);
+    dim3 grid((cap_p + kRaysPerBlock - 1) / kRaysPerBlock, P.n_seg), block(kTraceThreads);
+    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
     if (pass == 0) {
         if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, s, P, pass);
         else       hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, s, P, pass);
@@ -749,8 +780,8 @@ void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_c
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s)
 {
-    dim3 grid((n + 63) / 64), block(64);
-    const size_t lds = (size_t)P.stack_lds * 64 * sizeof(uint32_t);
+    dim3 grid((n + kRaysPerBlock - 1) / kRaysPerBlock), block(kTraceThreads);
+    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
     hipLaunchKernelGGL(k_debug_trace, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
 }
 
