@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- polar images/s of the radar hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A step = one polar image (400 azimuths x 3424 range bins, mono8) of the workload
+BASELINE.json's metric is quoted on (configs[1]): 400 azimuths x 200 rays, 1 ray-cast
+pass, 100k-triangle synthetic mesh, KAIST parameter preset (cfg/mulran_kaist_dyncfg.yaml)
+including the Perlin ambient-noise stage with injected per-column offsets.  Mesh, BVH,
+parameters and beam samples are resident in HBM before the timed region; poses are 7
+floats passed as kernel arguments; the image stays in HBM.
+
+N > 1 (north_star): the 400 azimuth columns of EVERY frame are sharded over the ranks
+(400/N columns each), one RCCL all-gather over xGMI assembles the frame on every rank
+-> total work per step is fixed: "scaling": "strong".
+
+Extra objects on the JSON line: "roofline" (dominant kernel = k_trace, hipEvent-timed on
+its launch stream inside the timed region) and, at N = 1 on rank 0, "cpu_baseline" (the
+CPU oracle = line-faithful port of RadarCPU::simulate, OpenMP over azimuths like
+RadarCPU.cpp:155, timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_wave_pass(n_tris):
+    """structure-independent floor D*64 + 4*48 + 132 with
+    D = ceil(log2(T/4)) BVH levels, 4 triangles tested, 132 B of wave state."""
+    d = int(math.ceil(math.log2(max(n_tris, 8) / 4.0)))
+    return d * 64 + 4 * 48 + 132
+
+
+WORKLOADS = {
+    # name: (scene config id, n_reflections, rays/beam)
+    "config2_100k_400x200_1pass": (2, 1, 200),
+    "config3_1M_400x200_4pass": (3, 4, 200),
+    "config4_10M_400x1000_4pass": (4, 4, 1000),
+    "target_10M_400x200_4pass": (4, 4, 200),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="config2_100k_400x200_1pass", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    ap.add_argument("--ambient-noise", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from radarays_ros_amd import native, params, scenes
+    from radarays_ros_amd.dist import AzimuthShard
+    from common import golden_beams, materials_for
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    scene_id, n_pass, n_rays = WORKLOADS[args.workload]
+    scene = scenes.config_scene(scene_id)
+    cfg = params.kaist_preset(n_reflections=n_pass, n_samples=n_rays, ambient_noise=args.ambient_noise)
+    mats = materials_for(scene)
+    beams = golden_beams(n_rays)
+    noise = (np.random.RandomState(7).uniform(0, 1, params.N_ANGLES) * 1000.0).astype(np.float32)
+    poses = scenes.trajectory(16, scene["name"])
+
+    ctx = native.Context(local_rank)
+    ctx.set_mesh(scene["verts"], scene["faces"], scene["face_object_id"])
+    ctx.set_materials(mats, scene["object_materials"], 0)
+    ctx.set_config(cfg, params.N_ANGLES)
+    ctx.set_beam_samples(beams)
+    ctx.set_noise_offsets(noise)
+    n_tris = len(scene["faces"])
+
+    shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank))
+    stream = torch.cuda.current_stream()
+
+    def step(k):
+        shard.frame(poses[k % len(poses)], stream)
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    # one instrumented frame outside the timed region: wave-pass count of this workload
+    shard.frame(poses[0], stream)
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    wave_passes_frame_rank = st["wave_passes"]
+    assert st["overflow"] == 0, st
+
+    ctx.set_timing_mode(2)          # hipEvents around k_trace only, on the launch stream
+    ctx.kernel_time("trace", reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    trace_ms, trace_launches = ctx.kernel_time("trace", reset=True)
+    ctx.set_timing_mode(0)
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        wp = torch.tensor([wave_passes_frame_rank], dtype=torch.int64, device="cuda")
+        dist.all_reduce(wp, op=dist.ReduceOp.SUM)
+        wave_passes_frame = int(wp.item())
+    else:
+        wave_passes_frame = wave_passes_frame_rank
+
+    out = None
+    if rank == 0:
+        img_per_s = args.steps / elapsed
+        b_wp = algorithmic_bytes_per_wave_pass(n_tris)
+        launches_per_frame = max(1, n_pass)
+        avg_trace_s = (trace_ms / max(trace_launches, 1)) * 1e-3
+        bytes_per_launch = wave_passes_frame_rank / launches_per_frame * b_wp
+        achieved = bytes_per_launch / avg_trace_s / 1e9 if avg_trace_s > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(args.workload, {}).get("k_trace_hbm_bytes_per_launch")
+        out = {
+            "metric": "polar images/sec (400 az x 3424 bins)",
+            "value": round(img_per_s, 2),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 rays / f64 energy+time",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "triangles": int(n_tris), "azimuths": params.N_ANGLES,
+                       "range_bins": int(cfg.n_cells), "rays_per_beam": n_rays, "passes": n_pass,
+                       "ambient_noise": int(cfg.ambient_noise),
+                       "sharding": "azimuth columns x%d + 1 RCCL all-gather/frame" % world if world > 1 else "single GPU"},
+            "rays_per_s": round(wave_passes_frame * img_per_s, 1),
+            "wave_passes_per_frame": int(wave_passes_frame),
+            "roofline": {"bound": "hbm", "kernel": "k_trace",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_wave_pass": b_wp,
+                         "avg_launch_us": round(avg_trace_s * 1e6, 2), "launches": int(trace_launches)},
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene, cfg, mats, beams, noise, poses, args.cpu_seconds)
+
+    shard.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s):
+    """The oracle (kind "port") on the host cores of this box, bounded sample."""
+    from oracle import oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    sc = O.Scene(scene["verts"], scene["faces"], scene["face_object_id"])
+    m = [x.astuple() for x in mats]
+    secs, frames = [], 0
+    t_wall = time.perf_counter()
+    k = 0
+    while True:
+        _, _, st = O.simulate(sc, m, scene["object_materials"], cfg, beams, poses[k % len(poses)],
+                              noise_rnd=noise, want_f32=False, n_threads=cores)
+        k += 1
+        if k > 2:                      # 2 warm-up frames (thread pool, caches)
+            secs.append(st["seconds"])
+            frames += 1
+        if (time.perf_counter() - t_wall > budget_s and frames >= 3) or frames >= 64:
+            break
+    med = float(np.median(secs))
+    return {"value": round(1.0 / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d full frames of the same workload (16-pose trajectory), median of the "
+                      "RadarCPU.cpp:147-550 stopwatch bracket, OpenMP over azimuths, in-repo SAH BVH2 "
+                      "(Embree absent)" % frames}
+
+
+if __name__ == "__main__":
+    main()

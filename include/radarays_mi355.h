@@ -166,7 +166,7 @@ int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* 
 /* average duration (ms) of the trace kernel launches since the last call with
  * reset!=0, measured with hipEvents on the launch stream when timing mode is
  * on; also returns the number of launches.  Used by bench.py for roofline. */
-int rr_set_timing_mode(rr_ctx* ctx, int enable);
+int rr_set_timing_mode(rr_ctx* ctx, int enable /* 0 off, 1 every kernel, 2 k_trace only */);
 int rr_get_kernel_time(rr_ctx* ctx, const char* kernel /* "trace"|"shade"|"scan"|"column"|"assemble" */,
                        double* total_ms, uint64_t* launches, int reset);
 

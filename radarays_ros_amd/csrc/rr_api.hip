@@ -77,6 +77,7 @@ struct rr_ctx {
     int smear_mode = 0;
 
     DevBuf<float4> d_qas, d_beams, d_materials;
+    DevBuf<uint32_t> d_beam_order;
     DevBuf<int32_t> d_objmat;
     DevBuf<float> d_smear, d_noise;
     bool tables_dirty = true;
@@ -94,7 +95,8 @@ struct rr_ctx {
     int last_n_seg = 0, last_n_passes = 0;
     int spill_stride = 0, stack_lds = 1;
 
-    bool stats_mode = false, timing = false;
+    bool stats_mode = false;
+    int timing = 0;   // 0 off, 1 every kernel, 2 k_trace only
     std::map<std::string, KernelTimer> timers;
 };
 
@@ -194,6 +196,34 @@ int upload_tables(rr_ctx* c)
     for (size_t i = 0; i < nb; i++) b4[i] = make_float4(c->beams[3 * i], c->beams[3 * i + 1], c->beams[3 * i + 2], 0.0f);
     RR_HIP(c, c->d_beams.ensure(nb));
     if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
+    {
+        // trace order of pass 0: Morton order of the direction's (y, z) so that a quad /
+        // wave holds neighbouring rays of the cone (RR_DEBUG bit 8 disables it)
+        std::vector<uint32_t> order(nb);
+        for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
+        const bool no_sort = getenv("RR_DEBUG") && (atoi(getenv("RR_DEBUG")) & 8);
+        if (nb > 1 && !no_sort) {
+            float lo[2] = { 1e30f, 1e30f }, hi[2] = { -1e30f, -1e30f };
+            for (size_t i = 0; i < nb; i++) for (int k = 0; k < 2; k++) {
+                lo[k] = std::min(lo[k], c->beams[3 * i + 1 + k]); hi[k] = std::max(hi[k], c->beams[3 * i + 1 + k]);
+            }
+            std::vector<uint32_t> code(nb);
+            for (size_t i = 0; i < nb; i++) {
+                uint32_t m = 0;
+                uint32_t u[2];
+                for (int k = 0; k < 2; k++) {
+                    const float e = hi[k] - lo[k];
+                    const float t = e > 0.f ? (c->beams[3 * i + 1 + k] - lo[k]) / e : 0.f;
+                    u[k] = (uint32_t)std::min(65535.0f, std::max(0.0f, t * 65535.0f));
+                }
+                for (int b = 0; b < 16; b++) m |= ((u[0] >> b) & 1u) << (2 * b) | ((u[1] >> b) & 1u) << (2 * b + 1);
+                code[i] = m;
+            }
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+        }
+        RR_HIP(c, c->d_beam_order.ensure(nb));
+        if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order.p, order.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
 
     std::vector<float4> m4(c->materials.size());
     for (size_t i = 0; i < m4.size(); i++)
@@ -262,7 +292,7 @@ void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_
     const rr_config& g = c->cfg;
     std::memset(&P, 0, sizeof(P));
     P.nodes = c->d_nodes.p; P.tris = c->d_tris.p;
-    P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.materials = c->d_materials.p;
+    P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.materials = c->d_materials.p;
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
     for (int k = 0; k < 2; k++) {
@@ -297,11 +327,13 @@ void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_
 
 struct TimedScope {
     rr_ctx* c; hipStream_t s; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    bool on;
     TimedScope(rr_ctx* c_, hipStream_t s_, const char* n_) : c(c_), s(s_), name(n_) {
-        if (c->timing) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+        on = c->timing == 1 || (c->timing == 2 && std::strcmp(name, "trace") == 0);
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~TimedScope() {
-        if (c->timing) { (void)hipEventRecord(b, s); c->timers[name].pending.emplace_back(a, b); }
+        if (on) { (void)hipEventRecord(b, s); c->timers[name].pending.emplace_back(a, b); }
     }
 };
 
@@ -399,7 +431,7 @@ void rr_destroy(rr_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
-    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release();
+    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_beam_order.release();
     for (int k = 0; k < 2; k++) { c->d_wA[k].release(); c->d_wB[k].release(); c->d_wC[k].release(); c->d_idx[k].release(); c->d_count[k].release(); }
     c->d_hit_tri.release(); c->d_sig_count.release(); c->d_spill.release(); c->d_cflag.release(); c->d_cols_u8.release();
     c->d_sigtmp.release(); c->d_sig.release(); c->d_hit_t.release(); c->d_cols_f32.release(); c->d_counters.release(); c->d_seg_stats.release();
@@ -537,6 +569,7 @@ int rr_get_stats(rr_ctx* c, rr_stats* st)
     Counters h;
     RR_HIP(c, hipMemcpy(&h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
     st->nodes_visited = h.nodes; st->tris_tested = h.tris; st->overflow = h.overflow;
+    if (getenv("RR_DEBUG")) fprintf(stderr, "[rr stats] waves %u wave_iters %llu (avg %.1f) max_iters %u\n", h.n_waves, h.wave_iters, h.n_waves ? (double)h.wave_iters / h.n_waves : 0.0, h.max_iters);
     const size_t n = (size_t)c->last_n_seg * (size_t)c->last_n_passes;
     if (n && c->d_seg_stats.p) {
         std::vector<SegStats> ss(n);
@@ -582,7 +615,7 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
 }
 
 int rr_set_stats_mode(rr_ctx* c, int enable) { if (!c) return -1; c->stats_mode = enable != 0; return 0; }
-int rr_set_timing_mode(rr_ctx* c, int enable) { if (!c) return -1; c->timing = enable != 0; return 0; }
+int rr_set_timing_mode(rr_ctx* c, int enable) { if (!c) return -1; c->timing = enable; return 0; }
 
 int rr_get_kernel_time(rr_ctx* c, const char* kernel, double* total_ms, uint64_t* launches, int reset)
 {

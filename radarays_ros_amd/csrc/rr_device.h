@@ -66,6 +66,8 @@ struct SigRec { int32_t cell; float strength; };
 
 struct Counters {
     unsigned long long nodes, tris;   // stats mode only (atomics)
+    unsigned long long wave_iters;    // sum over waves of traversal-loop iterations
+    unsigned int max_iters, n_waves;  // longest wave, wave count
     unsigned int overflow, pad;       // error bits, set on rare error paths
 };
 
@@ -80,6 +82,7 @@ struct Params {
     // per-config tables
     const float4* q_as;          // [n_angles] Tas.R (RadarCPU.cpp:202)
     const float4* beams;         // [n_beam] xyz
+    const uint32_t* beam_order;  // [n_beam] trace slot -> beam index (spatially sorted: coherent quads/waves)
     const float4* materials;     // [n_materials] velocity, ambient, diffuse, specular
     const int32_t* object_materials;
     const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)

@@ -86,7 +86,7 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
             const float2* bp = reinterpret_cast<const float2*>(np + 24 * q);
             const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];          // lo.x lo.y | lo.z hi.x | hi.y hi.z
             const uint4 ch = *reinterpret_cast<const uint4*>(np + 96);
-            if (STATS) n_nodes += (q == 0);
+            if (STATS) { n_nodes += (q == 0); }
             const float ax = __builtin_fmaf(b0.x, idx, oox), bx = __builtin_fmaf(b1.y, idx, oox);
             const float ay = __builtin_fmaf(b0.y, idy, ooy), by = __builtin_fmaf(b2.x, idy, ooy);
             const float az = __builtin_fmaf(b1.x, idz, ooz), bz = __builtin_fmaf(b2.y, idz, ooz);
@@ -146,6 +146,7 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
             }
         }
         // pop
+        if (STATS) n_tris += 0x10000u;   // high half: loop iterations of this lane
         if (sp == 0) break;
         sp--;
         cur = (sp < stack_lds) ? my[sp * kRaysPerWave] : spill[(size_t)(sp - stack_lds) * spill_stride + gray];
@@ -161,12 +162,15 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     extern __shared__ uint32_t lds_stack[];
     const int seg = blockIdx.y;
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-    const int j = blockIdx.x * kRaysPerBlock + r;
+    const int k = blockIdx.x * kRaysPerBlock + r;      // trace slot
     const int cur = pass & 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
     if ((int)(blockIdx.x * kRaysPerBlock) >= count) return;
-    const bool active = j < count;
+    const bool active = k < count;
+    // pass 0 is traced in a spatially sorted order of the beam samples; results are
+    // stored under the wave's own index j, so the reference order is untouched
+    const int j = (FIRST && active) ? (int)P.beam_order[k] : k;
 
     V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
     if (active) {
@@ -192,16 +196,20 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         const Hit h = traverse<STATS>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
                                       P.spill, P.spill_stride, gray, nn, nt);
         if (q == 0) {
-            const size_t k = (size_t)seg * P.cap + j;
-            P.hit_t[k] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
-            P.hit_tri[k] = h.tri;
+            const size_t hk = (size_t)seg * P.cap + j;
+            P.hit_t[hk] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
+            P.hit_tri[hk] = h.tri;
         }
     }
     if (STATS) {
-        for (int off = 32; off > 0; off >>= 1) { nn += __shfl_down(nn, off); nt += __shfl_down(nt, off); }
+        unsigned it = nt >> 16; nt &= 0xFFFFu;
+        for (int off = 32; off > 0; off >>= 1) { nn += __shfl_down(nn, off); nt += __shfl_down(nt, off); it = max(it, (unsigned)__shfl_down(it, off)); }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&P.counters->nodes, (unsigned long long)nn);
             atomicAdd(&P.counters->tris, (unsigned long long)nt);
+            atomicAdd(&P.counters->wave_iters, (unsigned long long)it);
+            atomicMax(&P.counters->max_iters, it);
+            atomicAdd(&P.counters->n_waves, 1u);
         }
     }
 }

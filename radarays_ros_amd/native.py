@@ -245,7 +245,7 @@ class Context:
         self._ck(self._L.rr_set_stats_mode(self._h, int(bool(on))))
 
     def set_timing_mode(self, on):
-        self._ck(self._L.rr_set_timing_mode(self._h, int(bool(on))))
+        self._ck(self._L.rr_set_timing_mode(self._h, int(on)))
 
     def kernel_time(self, name, reset=False):
         ms, n = C.c_double(), C.c_uint64()
