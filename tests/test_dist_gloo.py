@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the azimuth sharding contract
+(radarays_ros_amd/dist.py): partition -> per-rank column blocks -> ONE all-gather ->
+[n_angles][n_cells] in azimuth order -> mono8 image.  Column blocks come from the
+oracle here (no GPU); on the GPU box the same functions carry device tensors over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from radarays_ros_amd.dist import gather_columns, partition
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_partition_covers_all_azimuths():
+    for n, w in [(400, 1), (400, 2), (400, 8), (400, 3), (7, 8), (401, 4)]:
+        blocks = [partition(n, w, r) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        for (b0, e0), (b1, e1) in zip(blocks, blocks[1:]):
+            assert e0 == b1 and e0 >= b0
+        sizes = [e - b for b, e in blocks]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_angles, scroll, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from radarays_ros_amd import params, scenes
+    from common import golden_beams, mats_tuple
+    import gen_oracle_images as gen
+    s = gen.two_room_scene()
+    cfg = params.kaist_preset(n_reflections=2, ambient_noise=0, scroll_image=0, n_cells=512, resolution=0.1)
+    sc = O.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
+    mats = mats_tuple(params.kaist_materials() + [params.PENETRABLE])
+    b, e = partition(n_angles, world, rank)
+    # this rank's block, column-major [n_local][n_cells] (what rr_simulate_columns_device produces)
+    u8, _, _ = O.simulate(sc, mats, s["object_materials"], cfg, golden_beams(8), scenes.default_pose("box12"),
+                          az_begin=b, az_end=e, n_angles=n_angles, n_threads=1)
+    block = torch.from_numpy(np.ascontiguousarray(u8[:, b:e].T))
+    cols = gather_columns(block, n_angles, world)
+    assert cols.shape == (n_angles, cfg.n_cells)
+    # assemble like rr_assemble_image_device: img[c][(scroll + a) % A] = cols[a][c]
+    img = torch.roll(cols.t().contiguous(), shifts=scroll, dims=1)
+    if rank == 0:
+        full, _, _ = O.simulate(sc, mats, s["object_materials"], cfg.copy(scroll_image=scroll), golden_beams(8),
+                                scenes.default_pose("box12"), n_angles=n_angles, n_threads=1)
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([int(np.array_equal(img.numpy(), full))]))
+    # every rank holds the same frame
+    ref = img.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, img)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_angles,scroll", [(40, 0), (41, 5)])
+def test_two_rank_gather_assembles_the_frame(tmp_path, oracle, n_angles, scroll):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_angles, scroll, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(os.path.join(str(tmp_path), "ok.npy"))[0] == 1

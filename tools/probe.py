@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
 from common import golden_beams, materials_for
 cid = int(sys.argv[1]) if len(sys.argv) > 1 else 2
