@@ -52,6 +52,24 @@ struct KernelTimer {
 
 }  // namespace
 
+struct Lane {
+    int buf_seg = 0, buf_cap = 0, buf_sigcap = 0, buf_cells = 0;
+    DevBuf<float4> d_wA[2], d_wB[2];
+    DevBuf<double2> d_wC[2];
+    DevBuf<uint32_t> d_idx[2], d_count[2], d_hit_tri, d_sig_count, d_spill;
+    DevBuf<uint8_t> d_cflag, d_cols_u8;
+    DevBuf<SigRec> d_sigtmp, d_sig;
+    DevBuf<float> d_hit_t, d_cols_f32;
+    DevBuf<Counters> d_counters;
+    DevBuf<SegStats> d_seg_stats;
+    int last_n_seg = 0, last_n_passes = 0;
+    int spill_stride = 0, stack_lds = 1;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_consumed = nullptr;
+    bool pending_consume = false;
+};
+
 struct rr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -82,18 +100,10 @@ struct rr_ctx {
     DevBuf<float> d_smear, d_noise;
     bool tables_dirty = true;
 
-    // frame buffers
-    int buf_seg = 0, buf_cap = 0, buf_sigcap = 0, buf_cells = 0;
-    DevBuf<float4> d_wA[2], d_wB[2];
-    DevBuf<double2> d_wC[2];
-    DevBuf<uint32_t> d_idx[2], d_count[2], d_hit_tri, d_sig_count, d_spill;
-    DevBuf<uint8_t> d_cflag, d_cols_u8;
-    DevBuf<SigRec> d_sigtmp, d_sig;
-    DevBuf<float> d_hit_t, d_cols_f32;
-    DevBuf<Counters> d_counters;
-    DevBuf<SegStats> d_seg_stats;
-    int last_n_seg = 0, last_n_passes = 0;
-    int spill_stride = 0, stack_lds = 1;
+    // frame lanes: each owns a full set of frame buffers + a stream, so consecutive
+    // frames overlap on the GPU (the tail of one frame's k_trace runs beside the next frame)
+    std::vector<Lane> lanes;
+    size_t next_lane = 0, last_lane = 0;
 
     bool stats_mode = false;
     int timing = 0;   // 0 off, 1 every kernel, 2 k_trace only
@@ -172,6 +182,7 @@ int signal_capacity(const rr_config& cfg, int n_beam, int cap)
 int upload_tables(rr_ctx* c)
 {
     if (!c->tables_dirty) return 0;
+    RR_HIP(c, hipDeviceSynchronize());   // frames in flight on the lanes still read the old tables
     const rr_config& g = c->cfg;
     // Tas.R = EulerAngles{0,0,theta(angle)} -> quaternion (rmagine ZYX), RadarCPU.cpp:202
     std::vector<float4> qas((size_t)g.n_angles);
@@ -246,7 +257,7 @@ int upload_tables(rr_ctx* c)
     return 0;
 }
 
-int ensure_frame_buffers(rr_ctx* c, int n_seg, bool want_f32)
+int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
 {
     const rr_config& g = c->cfg;
     const int n_beam = (int)(c->beams.size() / 3);
@@ -259,34 +270,34 @@ int ensure_frame_buffers(rr_ctx* c, int n_seg, bool want_f32)
     if (S * per_seg > total_b / 2)
         return fail(c, -6, "wave queue capacity needs more than half of device memory; lower max_waves_per_azimuth");
     for (int k = 0; k < 2; k++) {
-        RR_HIP(c, c->d_wA[k].ensure(S * 2 * cap));
-        RR_HIP(c, c->d_wB[k].ensure(S * 2 * cap));
-        RR_HIP(c, c->d_wC[k].ensure(S * 2 * cap));
-        RR_HIP(c, c->d_idx[k].ensure(S * cap));
-        RR_HIP(c, c->d_count[k].ensure(S));
+        RR_HIP(c, L.d_wA[k].ensure(S * 2 * cap));
+        RR_HIP(c, L.d_wB[k].ensure(S * 2 * cap));
+        RR_HIP(c, L.d_wC[k].ensure(S * 2 * cap));
+        RR_HIP(c, L.d_idx[k].ensure(S * cap));
+        RR_HIP(c, L.d_count[k].ensure(S));
     }
-    RR_HIP(c, c->d_cflag.ensure(S * 2 * cap));
-    RR_HIP(c, c->d_sigtmp.ensure(S * 2 * cap));
-    RR_HIP(c, c->d_hit_t.ensure(S * cap));
-    RR_HIP(c, c->d_hit_tri.ensure(S * cap));
-    RR_HIP(c, c->d_sig.ensure(S * sigcap));
-    RR_HIP(c, c->d_sig_count.ensure(S));
-    RR_HIP(c, c->d_counters.ensure(1));
-    RR_HIP(c, c->d_seg_stats.ensure(S * (size_t)std::max(1, g.n_reflections)));
-    RR_HIP(c, c->d_cols_u8.ensure(S * g.n_cells));
-    if (want_f32) RR_HIP(c, c->d_cols_f32.ensure(S * g.n_cells));
+    RR_HIP(c, L.d_cflag.ensure(S * 2 * cap));
+    RR_HIP(c, L.d_sigtmp.ensure(S * 2 * cap));
+    RR_HIP(c, L.d_hit_t.ensure(S * cap));
+    RR_HIP(c, L.d_hit_tri.ensure(S * cap));
+    RR_HIP(c, L.d_sig.ensure(S * sigcap));
+    RR_HIP(c, L.d_sig_count.ensure(S));
+    RR_HIP(c, L.d_counters.ensure(1));
+    RR_HIP(c, L.d_seg_stats.ensure(S * (size_t)std::max(1, g.n_reflections)));
+    RR_HIP(c, L.d_cols_u8.ensure(S * g.n_cells));
+    if (want_f32) RR_HIP(c, L.d_cols_f32.ensure(S * g.n_cells));
     // traversal stack: LDS part + spill
-    c->stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 64));   // 64 B of LDS per entry per wave
-    const int spill_depth = (int)c->stack_need - c->stack_lds;
+    L.stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 64));   // 64 B of LDS per entry per wave
+    const int spill_depth = (int)c->stack_need - L.stack_lds;
     const size_t threads = S * (size_t)((cap + 63) / 64) * 64;
-    c->spill_stride = (int)threads;
-    if (spill_depth > 0) RR_HIP(c, c->d_spill.ensure((size_t)spill_depth * threads));
-    else RR_HIP(c, c->d_spill.ensure(1));
-    c->buf_seg = n_seg; c->buf_cap = cap; c->buf_sigcap = sigcap; c->buf_cells = g.n_cells;
+    L.spill_stride = (int)threads;
+    if (spill_depth > 0) RR_HIP(c, L.d_spill.ensure((size_t)spill_depth * threads));
+    else RR_HIP(c, L.d_spill.ensure(1));
+    L.buf_seg = n_seg; L.buf_cap = cap; L.buf_sigcap = sigcap; L.buf_cells = g.n_cells;
     return 0;
 }
 
-void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_seg,
+void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begin, int n_seg,
                  uint8_t* d_cols_u8, float* d_cols_f32)
 {
     const rr_config& g = c->cfg;
@@ -296,16 +307,16 @@ void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
     for (int k = 0; k < 2; k++) {
-        P.waves[k].A = c->d_wA[k].p; P.waves[k].B = c->d_wB[k].p; P.waves[k].C = c->d_wC[k].p;
-        P.idx[k] = c->d_idx[k].p; P.count[k] = c->d_count[k].p;
+        P.waves[k].A = L.d_wA[k].p; P.waves[k].B = L.d_wB[k].p; P.waves[k].C = L.d_wC[k].p;
+        P.idx[k] = L.d_idx[k].p; P.count[k] = L.d_count[k].p;
     }
-    P.cflag = c->d_cflag.p; P.sigtmp = c->d_sigtmp.p; P.hit_t = c->d_hit_t.p; P.hit_tri = c->d_hit_tri.p;
-    P.sig = c->d_sig.p; P.sig_count = c->d_sig_count.p; P.spill = c->d_spill.p; P.counters = c->d_counters.p; P.seg_stats = c->d_seg_stats.p;
+    P.cflag = L.d_cflag.p; P.sigtmp = L.d_sigtmp.p; P.hit_t = L.d_hit_t.p; P.hit_tri = L.d_hit_tri.p;
+    P.sig = L.d_sig.p; P.sig_count = L.d_sig_count.p; P.spill = L.d_spill.p; P.counters = L.d_counters.p; P.seg_stats = L.d_seg_stats.p;
     P.cols_u8 = d_cols_u8; P.cols_f32 = d_cols_f32;
     P.q_sm = { pose[0], pose[1], pose[2], pose[3] };
     P.t_sm = { pose[4], pose[5], pose[6] };
     P.az_begin = az_begin; P.n_seg = n_seg;
-    P.n_beam = (int)(c->beams.size() / 3); P.cap = c->buf_cap; P.sigcap = c->buf_sigcap;
+    P.n_beam = (int)(c->beams.size() / 3); P.cap = L.buf_cap; P.sigcap = L.buf_sigcap;
     P.n_cells = g.n_cells; P.n_angles = g.n_angles;
     P.n_materials = (int)c->materials.size(); P.n_objects = (int)c->object_materials.size();
     P.material_id_air = c->material_id_air;
@@ -320,7 +331,7 @@ void fill_params(rr_ctx* c, Params& P, const float pose[7], int az_begin, int n_
     P.noise_at_0 = g.ambient_noise_at_signal_0; P.noise_at_1 = g.ambient_noise_at_signal_1;
     P.noise_e_max = g.ambient_noise_energy_max; P.noise_e_min = g.ambient_noise_energy_min;
     P.noise_e_loss = g.ambient_noise_energy_loss;
-    P.spill_stride = c->spill_stride; P.stack_lds = c->stack_lds;
+    P.spill_stride = L.spill_stride; P.stack_lds = L.stack_lds;
     static const int dbg = getenv("RR_DEBUG") ? atoi(getenv("RR_DEBUG")) : 0;
     P.debug = dbg;
 }
@@ -347,7 +358,7 @@ int check_ready(rr_ctx* c)
     return 0;
 }
 
-int run_frame(rr_ctx* c, const float pose[7], int az_begin, int az_end,
+int run_frame(rr_ctx* c, Lane& L, const float pose[7], int az_begin, int az_end,
               uint8_t* d_cols_u8, float* d_cols_f32, hipStream_t s)
 {
     const rr_config& g = c->cfg;
@@ -358,14 +369,14 @@ int run_frame(rr_ctx* c, const float pose[7], int az_begin, int az_end,
     int rc = upload_tables(c); if (rc) return rc;
     const int n_beam = (int)(c->beams.size() / 3);
     const int cap = wave_capacity(g, n_beam);
-    if (n_seg > c->buf_seg || cap != c->buf_cap || g.n_cells != c->buf_cells ||
-        signal_capacity(g, n_beam, cap) != c->buf_sigcap) {
-        rc = ensure_frame_buffers(c, std::max(n_seg, c->buf_seg), false); if (rc) return rc;
+    if (n_seg > L.buf_seg || cap != L.buf_cap || g.n_cells != L.buf_cells ||
+        signal_capacity(g, n_beam, cap) != L.buf_sigcap) {
+        rc = ensure_frame_buffers(c, L, std::max(n_seg, L.buf_seg), false); if (rc) return rc;
     }
     Params P;
-    fill_params(c, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
-    if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), s));
-    c->last_n_seg = n_seg; c->last_n_passes = g.n_reflections;
+    fill_params(c, L, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
+    if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
+    L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
     for (int pass = 0; pass < g.n_reflections; pass++) {
         { TimedScope t(c, s, "trace"); launch_trace(P, pass, c->stats_mode, s); }
         { TimedScope t(c, s, "shade"); launch_shade(P, pass, s); }
@@ -421,6 +432,16 @@ rr_ctx* rr_create(int device)
         g_create_error = "rr_create: hipStreamCreate failed"; delete c; return nullptr;
     }
     rr_default_config(&c->cfg);
+    int n_lanes = getenv("RR_LANES") ? atoi(getenv("RR_LANES")) : 3;
+    n_lanes = std::max(1, std::min(n_lanes, 8));
+    c->lanes.resize((size_t)n_lanes);
+    for (Lane& L : c->lanes) {
+        if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&L.ev_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L.ev_consumed, hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "rr_create: lane stream/event creation failed"; rr_destroy(c); return nullptr;
+        }
+    }
     return c;
 }
 
@@ -432,9 +453,15 @@ void rr_destroy(rr_ctx* c)
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
     c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_beam_order.release();
-    for (int k = 0; k < 2; k++) { c->d_wA[k].release(); c->d_wB[k].release(); c->d_wC[k].release(); c->d_idx[k].release(); c->d_count[k].release(); }
-    c->d_hit_tri.release(); c->d_sig_count.release(); c->d_spill.release(); c->d_cflag.release(); c->d_cols_u8.release();
-    c->d_sigtmp.release(); c->d_sig.release(); c->d_hit_t.release(); c->d_cols_f32.release(); c->d_counters.release(); c->d_seg_stats.release();
+    for (Lane& L : c->lanes) {
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); }
+        L.d_hit_tri.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
+        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_seg_stats.release();
+        if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
+        if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -451,13 +478,13 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     RR_HIP(c, hipStreamSynchronize(c->stream));
     RR_HIP(c, c->d_nodes.ensure(bvh.nodes.size()));
     RR_HIP(c, hipMemcpy(c->d_nodes.p, bvh.nodes.data(), bvh.nodes.size() * sizeof(Node4), hipMemcpyHostToDevice));
-    RR_HIP(c, c->d_tris.ensure(bvh.tris.size()));
+    RR_HIP(c, c->d_tris.ensure(bvh.tris.size() + 4));   // +4: a quad may fetch past a short leaf
     if (!bvh.tris.empty())
         RR_HIP(c, hipMemcpy(c->d_tris.p, bvh.tris.data(), bvh.tris.size() * sizeof(TriRec), hipMemcpyHostToDevice));
     c->n_nodes = bvh.nodes.size(); c->n_tris = bvh.tris.size();
     c->depth = bvh.depth; c->stack_need = bvh.stack_need;
     c->have_mesh = true;
-    c->buf_seg = 0;   // stack geometry may have changed
+    for (Lane& L : c->lanes) { if (L.stream) RR_HIP(c, hipStreamSynchronize(L.stream)); L.buf_seg = 0; }   // stack geometry may have changed
     return 0;
 }
 
@@ -523,7 +550,8 @@ int rr_simulate_columns_device(rr_ctx* c, const float pose[7], int az_begin, int
     int rc = check_ready(c); if (rc) return rc;
     if (!pose || !d_cols_u8) return fail(c, -3, "rr_simulate_columns_device: null pose/output");
     RR_HIP(c, hipSetDevice(c->device));
-    return run_frame(c, pose, az_begin, az_end, d_cols_u8, d_cols_f32, stream ? (hipStream_t)stream : c->stream);
+    c->last_lane = 0;
+    return run_frame(c, c->lanes[0], pose, az_begin, az_end, d_cols_u8, d_cols_f32, stream ? (hipStream_t)stream : c->stream);
 }
 
 int rr_assemble_image_device(rr_ctx* c, const uint8_t* d_cols_u8, uint8_t* d_img_u8, void* stream)
@@ -543,18 +571,39 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
     int rc = check_ready(c); if (rc) return rc;
     if (!pose || !d_img_u8) return fail(c, -3, "rr_simulate_device: null pose/output");
     RR_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t user = stream ? (hipStream_t)stream : c->stream;
     rc = upload_tables(c); if (rc) return rc;
-    if (c->buf_seg < c->cfg.n_angles) { rc = ensure_frame_buffers(c, c->cfg.n_angles, false); if (rc) return rc; }
-    RR_HIP(c, c->d_cols_u8.ensure((size_t)c->cfg.n_angles * c->cfg.n_cells));
-    rc = run_frame(c, pose, 0, c->cfg.n_angles, c->d_cols_u8.p, nullptr, s); if (rc) return rc;
-    return rr_assemble_image_device(c, c->d_cols_u8.p, d_img_u8, s);
+    const int A = c->cfg.n_angles;
+    if (c->lanes.size() == 1) {
+        Lane& L = c->lanes[0];
+        c->last_lane = 0;
+        if (L.buf_seg < A) { rc = ensure_frame_buffers(c, L, A, false); if (rc) return rc; }
+        rc = run_frame(c, L, pose, 0, A, L.d_cols_u8.p, nullptr, user); if (rc) return rc;
+        return rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user);
+    }
+    // Frame pipelining: trace/shade/scan/column of this frame run on the lane's own stream
+    // (no dependency on the caller's stream), only the assemble -- the one kernel that touches
+    // the caller's buffer -- is ordered on the caller's stream.  The lane is reused only after
+    // that assemble has consumed its columns.
+    const size_t li = c->next_lane++ % c->lanes.size();
+    Lane& L = c->lanes[li];
+    c->last_lane = li;
+    if (L.buf_seg < A) { rc = ensure_frame_buffers(c, L, A, false); if (rc) return rc; }
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(L.stream, L.ev_consumed, 0));
+    rc = run_frame(c, L, pose, 0, A, L.d_cols_u8.p, nullptr, L.stream); if (rc) return rc;
+    RR_HIP(c, hipEventRecord(L.ev_ready, L.stream));
+    RR_HIP(c, hipStreamWaitEvent(user, L.ev_ready, 0));
+    rc = rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user); if (rc) return rc;
+    RR_HIP(c, hipEventRecord(L.ev_consumed, user));
+    L.pending_consume = true;
+    return 0;
 }
 
 int rr_synchronize(rr_ctx* c, void* stream)
 {
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
+    for (Lane& L : c->lanes) RR_HIP(c, hipStreamSynchronize(L.stream));
     RR_HIP(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
     return 0;
 }
@@ -565,15 +614,16 @@ int rr_get_stats(rr_ctx* c, rr_stats* st)
     RR_HIP(c, hipSetDevice(c->device));
     RR_HIP(c, hipDeviceSynchronize());
     std::memset(st, 0, sizeof(*st));
-    if (!c->d_counters.p) return 0;
+    Lane& L = c->lanes[c->last_lane];
+    if (!L.d_counters.p) return 0;
     Counters h;
-    RR_HIP(c, hipMemcpy(&h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
     st->nodes_visited = h.nodes; st->tris_tested = h.tris; st->overflow = h.overflow;
     if (getenv("RR_DEBUG")) fprintf(stderr, "[rr stats] waves %u wave_iters %llu (avg %.1f) max_iters %u\n", h.n_waves, h.wave_iters, h.n_waves ? (double)h.wave_iters / h.n_waves : 0.0, h.max_iters);
-    const size_t n = (size_t)c->last_n_seg * (size_t)c->last_n_passes;
-    if (n && c->d_seg_stats.p) {
+    const size_t n = (size_t)L.last_n_seg * (size_t)L.last_n_passes;
+    if (n && L.d_seg_stats.p) {
         std::vector<SegStats> ss(n);
-        RR_HIP(c, hipMemcpy(ss.data(), c->d_seg_stats.p, n * sizeof(SegStats), hipMemcpyDeviceToHost));
+        RR_HIP(c, hipMemcpy(ss.data(), L.d_seg_stats.p, n * sizeof(SegStats), hipMemcpyDeviceToHost));
         for (const SegStats& x : ss) { st->wave_passes += x.wave_passes; st->hits += x.hits; st->signals += x.signals; }
     }
     return 0;
@@ -590,14 +640,17 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
     const int n_seg = az_end - az_begin;
     if (n_seg == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return 0; }
     rc = upload_tables(c); if (rc) return rc;
-    rc = ensure_frame_buffers(c, std::max(n_seg, c->buf_seg), out_f32 != nullptr); if (rc) return rc;
-    if (out_f32) RR_HIP(c, c->d_cols_f32.ensure((size_t)c->buf_seg * g.n_cells));
-    rc = run_frame(c, pose, az_begin, az_end, c->d_cols_u8.p, out_f32 ? c->d_cols_f32.p : nullptr, c->stream);
+    Lane& L = c->lanes[0];
+    c->last_lane = 0;
+    RR_HIP(c, hipDeviceSynchronize());
+    rc = ensure_frame_buffers(c, L, std::max(n_seg, L.buf_seg), out_f32 != nullptr); if (rc) return rc;
+    if (out_f32) RR_HIP(c, L.d_cols_f32.ensure((size_t)L.buf_seg * g.n_cells));
+    rc = run_frame(c, L, pose, az_begin, az_end, L.d_cols_u8.p, out_f32 ? L.d_cols_f32.p : nullptr, c->stream);
     if (rc) return rc;
     std::vector<uint8_t> h8((size_t)n_seg * g.n_cells);
     std::vector<float> hf(out_f32 ? (size_t)n_seg * g.n_cells : 0);
-    RR_HIP(c, hipMemcpyAsync(h8.data(), c->d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
-    if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), c->d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RR_HIP(c, hipMemcpyAsync(h8.data(), L.d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
+    if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), L.d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     RR_HIP(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < n_seg; s++) {
         const int col = (g.scroll_image + az_begin + s) % g.n_angles;   // RadarCPU.cpp:457

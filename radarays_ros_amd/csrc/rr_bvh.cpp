@@ -166,23 +166,22 @@ struct Collapser {
         // empty slot: a degenerate box at +3e38 -- the slab test then yields t = +-huge
         // on every axis and can never pass (inverted +-inf boxes would: min/max reorder them)
         for (int i = 0; i < 4; i++) {
-            for (int k = 0; k < 6; k++) nd.box[i][k] = kEmptyCoord;
-            nd.child[i] = kEmptyRef; nd.meta[i] = 0;
+            for (int k = 0; k < 3; k++) nd.c[i].lo[k] = nd.c[i].hi[k] = kEmptyCoord;
+            nd.c[i].ref = kEmptyRef; nd.c[i].pad = 0;
         }
-        nd.meta[0] = (uint32_t)nc;
         uint32_t depth = 0, need = 0;
         uint32_t inner_self[4];
         for (int i = 0; i < nc; i++) {
             const Node2& c = n2[cand[i]];
-            for (int k = 0; k < 3; k++) { nd.box[i][k] = c.box.lo[k] - inflate; nd.box[i][3 + k] = c.box.hi[k] + inflate; }
+            for (int k = 0; k < 3; k++) { nd.c[i].lo[k] = c.box.lo[k] - inflate; nd.c[i].hi[k] = c.box.hi[k] + inflate; }
             if (c.count) {
-                nd.child[i] = emit_leaf(c);
+                nd.c[i].ref = emit_leaf(c);
                 sah += (double)c.box.half_area() * c.count;
                 inner_self[i] = 0xFFFFFFFFu;
             } else {
                 inner_self[i] = (uint32_t)out.nodes.size();
                 out.nodes.emplace_back();
-                nd.child[i] = inner_self[i];
+                nd.c[i].ref = inner_self[i];
                 sah += (double)c.box.half_area();
             }
         }
@@ -215,8 +214,8 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
     if (nf == 0) {
         Node4 nd;
         for (int i = 0; i < 4; i++) {
-            for (int k = 0; k < 6; k++) nd.box[i][k] = kEmptyCoord;
-            nd.child[i] = kEmptyRef; nd.meta[i] = 0;
+            for (int k = 0; k < 3; k++) nd.c[i].lo[k] = nd.c[i].hi[k] = kEmptyCoord;
+            nd.c[i].ref = kEmptyRef; nd.c[i].pad = 0;
         }
         out.nodes.push_back(nd);
         out.depth = 1; out.stack_need = 0;

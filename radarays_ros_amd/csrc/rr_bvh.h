@@ -22,13 +22,18 @@ constexpr uint32_t kEmptyRef = 0x7FFFFFFFu;
 constexpr uint32_t kMaxLeafTris = 4;
 constexpr float kEmptyCoord = 3.0e38f;
 
-// Child boxes are AoS (24 B each): the traversal kernel puts ONE RAY ON A QUAD of
-// lanes, lane q tests child q, so lane q fetches box[q] with three 8-byte loads and
-// all four lanes fetch child[] with one 16-byte load.
+// One RAY is traced by a QUAD of lanes; lane q owns child q.  A node is four 32-byte
+// child records, so lane q fetches everything it needs (box + child reference) with
+// two 16-byte loads from one address -- the same shape as a triangle fetch, which
+// lets the kernel issue ONE batch of loads per traversal step whatever the step is.
+struct alignas(16) Child4 {
+    float lo[3];
+    float hi[3];
+    uint32_t ref;       // see encoding above
+    uint32_t pad;
+};
 struct alignas(16) Node4 {
-    float box[4][6];    // lo.xyz, hi.xyz
-    uint32_t child[4];
-    uint32_t meta[4];   // meta[0] = number of used children; rest reserved
+    Child4 c[4];
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be one 128-byte line");
 

@@ -80,43 +80,49 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     uint32_t cur = 0;   // root
 
 #define RR_PUSH(r) { if (q == 0) { if (sp < stack_lds) my[sp * kRaysPerWave] = (r); else spill[(size_t)(sp - stack_lds) * spill_stride + gray] = (r); } sp++; }
+    const float4* node4 = reinterpret_cast<const float4*>(nodes);   // 8 float4 per node, 2 per child
+    const float4* tri4 = reinterpret_cast<const float4*>(tris);     // 3 float4 per triangle
     while (true) {
-        if (!(cur & kLeafFlag)) {
-            const char* np = reinterpret_cast<const char*>(nodes + cur);
-            const float2* bp = reinterpret_cast<const float2*>(np + 24 * q);
-            const float2 b0 = bp[0], b1 = bp[1], b2 = bp[2];          // lo.x lo.y | lo.z hi.x | hi.y hi.z
-            const uint4 ch = *reinterpret_cast<const uint4*>(np + 96);
+        // ---- ONE batch of loads per step, whatever the step is (single s_waitcnt) ----
+        const bool leaf = (cur & kLeafFlag) != 0;
+        const uint32_t first = cur & 0x0FFFFFFFu;
+        const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+        const float4* p = leaf ? (tri4 + 3 * (size_t)(first + q)) : (node4 + 8 * (size_t)cur + 2 * q);
+        const float4 A = p[0], B = p[1];
+        float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (leaf) C = p[2];          // triangle arrays are padded: q >= cnt reads stay in bounds
+        if (!leaf) {
+            // child record: A = (lo.x lo.y lo.z hi.x)  B = (hi.y hi.z ref pad)
             if (STATS) { n_nodes += (q == 0); }
-            const float ax = __builtin_fmaf(b0.x, idx, oox), bx = __builtin_fmaf(b1.y, idx, oox);
-            const float ay = __builtin_fmaf(b0.y, idy, ooy), by = __builtin_fmaf(b2.x, idy, ooy);
-            const float az = __builtin_fmaf(b1.x, idz, ooz), bz = __builtin_fmaf(b2.y, idz, ooz);
+            const float ax = __builtin_fmaf(A.x, idx, oox), bx = __builtin_fmaf(A.w, idx, oox);
+            const float ay = __builtin_fmaf(A.y, idy, ooy), by = __builtin_fmaf(B.x, idy, ooy);
+            const float az = __builtin_fmaf(A.z, idz, ooz), bz = __builtin_fmaf(B.y, idz, ooz);
             const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
             const bool h = (tmin <= tmax) && (tmin <= tcull);
             const uint32_t mykey = h ? ((__float_as_uint(tmin) & ~3u) | (uint32_t)q) : (0x7F800000u | (uint32_t)q);
+            const uint32_t myref = __float_as_uint(B.z);
             uint32_t k0 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST0), k1 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST1);
             uint32_t k2 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST2), k3 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST3);
+            const uint32_t r0 = (uint32_t)RR_DPP_I(myref, RR_QBCAST0), r1 = (uint32_t)RR_DPP_I(myref, RR_QBCAST1);
+            const uint32_t r2 = (uint32_t)RR_DPP_I(myref, RR_QBCAST2), r3 = (uint32_t)RR_DPP_I(myref, RR_QBCAST3);
             // sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest first; identical in all 4 lanes
 #define RR_CSWAP(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
             RR_CSWAP(k0, k1) RR_CSWAP(k2, k3) RR_CSWAP(k0, k2) RR_CSWAP(k1, k3) RR_CSWAP(k1, k2)
 #undef RR_CSWAP
-#define RR_REF(k) (((k) & 3u) == 0u ? ch.x : ((k) & 3u) == 1u ? ch.y : ((k) & 3u) == 2u ? ch.z : ch.w)
+#define RR_REF(k) (((k) & 3u) == 0u ? r0 : ((k) & 3u) == 1u ? r1 : ((k) & 3u) == 2u ? r2 : r3)
             if (k3 < 0x7F800000u) RR_PUSH(RR_REF(k3))
             if (k2 < 0x7F800000u) RR_PUSH(RR_REF(k2))
             if (k1 < 0x7F800000u) RR_PUSH(RR_REF(k1))
             if (k0 < 0x7F800000u) { cur = RR_REF(k0); continue; }
 #undef RR_REF
         } else {
-            const uint32_t first = cur & 0x0FFFFFFFu;
-            const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
             float t = __builtin_inff();
             uint32_t face = 0xFFFFFFFFu, tri = 0xFFFFFFFFu;
             if ((uint32_t)q < cnt) {
-                const float4* tp = reinterpret_cast<const float4*>(tris + (first + q));
-                const float4 a = tp[0], b = tp[1], c = tp[2];
                 if (STATS) n_tris++;
                 // Moeller-Trumbore, f32, un-fused: bit-identical to the CPU restatement
-                const V3 v0 = { a.x, a.y, a.z }, e1 = { b.x, b.y, b.z }, e2 = { c.x, c.y, c.z };
+                const V3 v0 = { A.x, A.y, A.z }, e1 = { B.x, B.y, B.z }, e2 = { C.x, C.y, C.z };
                 const V3 pvec = v_cross(d, e2);
                 const float det = v_dot(e1, pvec);
                 const float inv = 1.0f / det;
@@ -127,7 +133,7 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
                 const float tt = v_dot(e2, qvec) * inv;
                 const bool ok = (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
                                 (tt > 0.0f && tt <= range_max);
-                if (ok) { t = tt; face = __float_as_uint(a.w); tri = first + q; }
+                if (ok) { t = tt; face = __float_as_uint(A.w); tri = first + q; }
             }
             // quad-wide nearest (t, then lower face index)
             {
@@ -193,8 +199,10 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     unsigned nn = 0, nt = 0;
     if (active) {
         const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
-        const Hit h = traverse<STATS>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
-                                      P.spill, P.spill_stride, gray, nn, nt);
+        Hit h; h.t = 1.0f; h.tri = 0; h.face = 0;
+        if (!(P.debug & 32))
+            h = traverse<STATS>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
+                                P.spill, P.spill_stride, gray, nn, nt);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
             P.hit_t[hk] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
@@ -510,7 +518,6 @@ __constant__ unsigned char c_perm[256] = {
     181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93,
     222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180
 };
-__device__ inline int perm(int i) { return c_perm[i & 255]; }
 __device__ inline double p_fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }
 __device__ inline double p_lerp(double t, double a, double b) { return a + t * (b - a); }
 __device__ inline double p_grad(int hash, double x, double y, double z)
@@ -520,19 +527,18 @@ __device__ inline double p_grad(int hash, double x, double y, double z)
     const double v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
     return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
 }
-__device__ inline double perlin_noise(double sx, double sy)
+// perlin_noise(x, y, z = 0) of image_algorithms.h:69-106 with the permutation table in LDS.
+// For z = 0: Z = 0, w = fade(0) = 0, and lerp(0, a, b) = a + 0*(b - a) = a exactly (b - a is
+// finite), so the z-1 half of the lattice is not evaluated -- bit-identical result.
+__device__ inline double perlin_noise(const unsigned char* pt, double sx, double sy)
 {
-    const double sz = 0.0;
-    const int X = (int)floor(sx) & 255, Y = (int)floor(sy) & 255, Z = (int)floor(sz) & 255;
-    const double x = sx - floor(sx), y = sy - floor(sy), z = sz - floor(sz);
-    const double u = p_fade(x), v = p_fade(y), w = p_fade(z);
-    const int A = perm(X) + Y, AA = perm(A) + Z, AB = perm(A + 1) + Z;
-    const int B = perm(X + 1) + Y, BA = perm(B) + Z, BB = perm(B + 1) + Z;
-    return p_lerp(w,
-        p_lerp(v, p_lerp(u, p_grad(perm(AA), x, y, z), p_grad(perm(BA), x - 1, y, z)),
-                  p_lerp(u, p_grad(perm(AB), x, y - 1, z), p_grad(perm(BB), x - 1, y - 1, z))),
-        p_lerp(v, p_lerp(u, p_grad(perm(AA + 1), x, y, z - 1), p_grad(perm(BA + 1), x - 1, y, z - 1)),
-                  p_lerp(u, p_grad(perm(AB + 1), x, y - 1, z - 1), p_grad(perm(BB + 1), x - 1, y - 1, z - 1))));
+    const int X = (int)floor(sx) & 255, Y = (int)floor(sy) & 255;
+    const double x = sx - floor(sx), y = sy - floor(sy), z = 0.0;
+    const double u = p_fade(x), v = p_fade(y);
+    const int A = pt[X] + Y, AA = pt[A & 255], AB = pt[(A + 1) & 255];
+    const int B = pt[(X + 1) & 255] + Y, BA = pt[B & 255], BB = pt[(B + 1) & 255];
+    return p_lerp(v, p_lerp(u, p_grad(pt[AA], x, y, z), p_grad(pt[BA], x - 1, y, z)),
+                     p_lerp(u, p_grad(pt[AB], x, y - 1, z), p_grad(pt[BB], x - 1, y - 1, z)));
 }
 
 // defined variate stream for ambient_noise == 1 (the reference draws from
@@ -572,6 +578,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     __shared__ float s_w[256];
     __shared__ unsigned long long s_tiles[2];
     __shared__ float s_red[kColWaves];
+    __shared__ unsigned char s_perm[256];
 
     const int seg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 
     for (int i = tid; i < n_cells; i += kColThreads) lds_col[i] = 0.0f;
     if (tid < W && P.signal_denoising > 0) s_w[tid] = P.smear[tid];
+    if (tid < 256) s_perm[tid] = c_perm[tid];
     __syncthreads();
 
     int n_valid_last = 0, n_hit_last = 0;
@@ -690,8 +698,8 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 p = (double)uniform01((uint32_t)(int)rnd, (uint32_t)col, (uint32_t)i);
             } else if (P.ambient_noise == 2) {
                 const double random_begin = (double)rnd;
-                const double p1 = perlin_noise(random_begin + (double)i * 0.05, (double)col * 0.05);
-                const double p2 = perlin_noise(random_begin + (double)i * 0.2, (double)col * 0.2);
+                const double p1 = perlin_noise(s_perm, random_begin + (double)i * 0.05, (double)col * 0.05);
+                const double p2 = perlin_noise(s_perm, random_begin + (double)i * 0.2, (double)col * 0.2);
                 p = 0.9 * p1 + 0.1 * p2;
             }
             const float signal_max = max_val;
@@ -699,7 +707,10 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
             const float signal_ = (float)(1.0 - (double)((signal - 0.0f) / signal_amp));
             const float noise_at_0 = (float)((double)signal_amp * P.noise_at_0);
             const float noise_at_1 = (float)((double)signal_amp * P.noise_at_1);
-            const float signal__ = (float)pow((double)signal_, 4.0);
+            // std::pow(signal_, 4.0) (RadarCPU.cpp:509): two exact-order squarings in f64 differ from a
+            // correctly rounded pow by < 1.5 ulp(f64), invisible after the narrowing to f32
+            const double sg2 = (double)signal_ * (double)signal_;
+            const float signal__ = (float)(sg2 * sg2);
             const float noise_amp = (float)((double)(signal__ * noise_at_0) + (1.0 - (double)signal__) * (double)noise_at_1);
             const float noise_energy_max = (float)((double)signal_max * P.noise_e_max);
             const float noise_energy_min = (float)((double)signal_max * P.noise_e_min);

@@ -23,8 +23,9 @@ c.set_stats_mode(True); c.simulate_device(poses[0], img.data_ptr(), st); print("
 K = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 t0 = time.time()
 for k in range(K): c.simulate_device(poses[k % 16], img.data_ptr(), st)
+t_enq = time.time() - t0
 torch.cuda.synchronize(); dt = time.time() - t0
-print("frames/s %.1f  ms/frame %.3f" % (K / dt, 1e3 * dt / K))
+print("frames/s %.1f  ms/frame %.3f  (host enqueue %.1f us/frame)" % (K / dt, 1e3 * dt / K, 1e6 * t_enq / K))
 c.set_timing_mode(1)
 for k in range(K): c.simulate_device(poses[k % 16], img.data_ptr(), st)
 torch.cuda.synchronize()
