@@ -56,7 +56,7 @@ struct Lane {
     int buf_seg = 0, buf_cap = 0, buf_sigcap = 0, buf_cells = 0;
     DevBuf<float4> d_wA[2], d_wB[2];
     DevBuf<double2> d_wC[2];
-    DevBuf<uint32_t> d_idx[2], d_count[2], d_hit_tri, d_sig_count, d_spill;
+    DevBuf<uint32_t> d_idx[2], d_count[2], d_torder[2], d_refpos, d_hit_tri, d_sig_count, d_spill;
     DevBuf<uint8_t> d_cflag, d_cols_u8;
     DevBuf<SigRec> d_sigtmp, d_sig;
     DevBuf<float> d_hit_t, d_cols_f32;
@@ -274,9 +274,11 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
         RR_HIP(c, L.d_wB[k].ensure(S * 2 * cap));
         RR_HIP(c, L.d_wC[k].ensure(S * 2 * cap));
         RR_HIP(c, L.d_idx[k].ensure(S * cap));
+        RR_HIP(c, L.d_torder[k].ensure(S * cap));
         RR_HIP(c, L.d_count[k].ensure(S));
     }
     RR_HIP(c, L.d_cflag.ensure(S * 2 * cap));
+    RR_HIP(c, L.d_refpos.ensure(S * 2 * cap));
     RR_HIP(c, L.d_sigtmp.ensure(S * 2 * cap));
     RR_HIP(c, L.d_hit_t.ensure(S * cap));
     RR_HIP(c, L.d_hit_tri.ensure(S * cap));
@@ -308,8 +310,9 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
     for (int k = 0; k < 2; k++) {
         P.waves[k].A = L.d_wA[k].p; P.waves[k].B = L.d_wB[k].p; P.waves[k].C = L.d_wC[k].p;
-        P.idx[k] = L.d_idx[k].p; P.count[k] = L.d_count[k].p;
+        P.idx[k] = L.d_idx[k].p; P.count[k] = L.d_count[k].p; P.torder[k] = L.d_torder[k].p;
     }
+    P.refpos = L.d_refpos.p;
     P.cflag = L.d_cflag.p; P.sigtmp = L.d_sigtmp.p; P.hit_t = L.d_hit_t.p; P.hit_tri = L.d_hit_tri.p;
     P.sig = L.d_sig.p; P.sig_count = L.d_sig_count.p; P.spill = L.d_spill.p; P.counters = L.d_counters.p; P.seg_stats = L.d_seg_stats.p;
     P.cols_u8 = d_cols_u8; P.cols_f32 = d_cols_f32;
@@ -332,6 +335,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.noise_e_max = g.ambient_noise_energy_max; P.noise_e_min = g.ambient_noise_energy_min;
     P.noise_e_loss = g.ambient_noise_energy_loss;
     P.spill_stride = L.spill_stride; P.stack_lds = L.stack_lds;
+    P.spill_depth = std::max(0, (int)c->stack_need - L.stack_lds);
     static const int dbg = getenv("RR_DEBUG") ? atoi(getenv("RR_DEBUG")) : 0;
     P.debug = dbg;
 }
@@ -455,7 +459,8 @@ void rr_destroy(rr_ctx* c)
     c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_beam_order.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); }
+        for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
+        L.d_refpos.release();
         L.d_hit_tri.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
         L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_seg_stats.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
@@ -714,7 +719,7 @@ int rr_debug_trace(rr_ctx* c, const float* origs, const float* dirs, size_t n, f
     RR_HIP(c, d_f.ensure(chunk)); RR_HIP(c, d_spill.ensure(spill_depth > 0 ? (size_t)spill_depth * chunk : 1));
     Params P; std::memset(&P, 0, sizeof(P));
     P.nodes = c->d_nodes.p; P.tris = c->d_tris.p; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
-    P.spill = d_spill.p; P.spill_stride = (int)chunk; P.stack_lds = stack_lds;
+    P.spill = d_spill.p; P.spill_stride = (int)chunk; P.stack_lds = stack_lds; P.spill_depth = std::max(0, spill_depth);
     int rc = 0;
     for (size_t b = 0; b < n && !rc; b += chunk) {
         const size_t m = std::min(chunk, n - b);

@@ -91,6 +91,8 @@ struct Params {
     WaveBuf waves[2];            // [n_seg][2*cap] child slots, ping-pong by pass parity
     uint32_t* idx[2];            // [n_seg][cap] live slot list
     uint32_t* count[2];          // [n_seg]
+    uint32_t* torder[2];         // [n_seg][cap] trace slot -> position in idx (coherent order, inherited from pass 0)
+    uint32_t* refpos;            // [n_seg][2*cap] child slot -> its position in the next pass' idx
     uint8_t* cflag;              // [n_seg][2*cap] child alive flags (+ bit2 on slot 2j: hit)
     SigRec* sigtmp;              // [n_seg][2*cap] per-wave signal slots (path, air)
     float* hit_t;                // [n_seg][cap]
@@ -114,7 +116,7 @@ struct Params {
     float energy_max_f;          // (float)energy_max  (cv convertTo alpha)
     double signal_max;
     double noise_at_0, noise_at_1, noise_e_max, noise_e_min, noise_e_loss;
-    int spill_stride, stack_lds;
+    int spill_stride, stack_lds, spill_depth;
     int debug;                   // RR_DEBUG env bits (perf experiments only)
 };
 

@@ -56,7 +56,7 @@ constexpr int kRaysPerBlock = kTraceThreads / 4;
 #define RR_QXOR1 0xB1
 #define RR_QXOR2 0x4E
 
-template <bool STATS>
+template <bool STATS, bool SPILL>
 __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris,
                                V3 o, V3 d, float range_max,
                                uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gray,
@@ -79,9 +79,9 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     int sp = 0;
     uint32_t cur = 0;   // root
 
-#define RR_PUSH(r) { if (q == 0) { if (sp < stack_lds) my[sp * kRaysPerWave] = (r); else spill[(size_t)(sp - stack_lds) * spill_stride + gray] = (r); } sp++; }
     const float4* node4 = reinterpret_cast<const float4*>(nodes);   // 8 float4 per node, 2 per child
     const float4* tri4 = reinterpret_cast<const float4*>(tris);     // 3 float4 per triangle
+    const int qsh = (threadIdx.x & 63) & ~3;                        // bit position of this quad in a ballot
     while (true) {
         // ---- ONE batch of loads per step, whatever the step is (single s_waitcnt) ----
         const bool leaf = (cur & kLeafFlag) != 0;
@@ -100,22 +100,25 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
             const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
             const bool h = (tmin <= tmax) && (tmin <= tcull);
+            // distinct keys (lane id in the low bits); a miss sorts last
             const uint32_t mykey = h ? ((__float_as_uint(tmin) & ~3u) | (uint32_t)q) : (0x7F800000u | (uint32_t)q);
             const uint32_t myref = __float_as_uint(B.z);
-            uint32_t k0 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST0), k1 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST1);
-            uint32_t k2 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST2), k3 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST3);
-            const uint32_t r0 = (uint32_t)RR_DPP_I(myref, RR_QBCAST0), r1 = (uint32_t)RR_DPP_I(myref, RR_QBCAST1);
-            const uint32_t r2 = (uint32_t)RR_DPP_I(myref, RR_QBCAST2), r3 = (uint32_t)RR_DPP_I(myref, RR_QBCAST3);
-            // sorting network (0,1)(2,3)(0,2)(1,3)(1,2): nearest first; identical in all 4 lanes
-#define RR_CSWAP(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
-            RR_CSWAP(k0, k1) RR_CSWAP(k2, k3) RR_CSWAP(k0, k2) RR_CSWAP(k1, k3) RR_CSWAP(k1, k2)
-#undef RR_CSWAP
-#define RR_REF(k) (((k) & 3u) == 0u ? r0 : ((k) & 3u) == 1u ? r1 : ((k) & 3u) == 2u ? r2 : r3)
-            if (k3 < 0x7F800000u) RR_PUSH(RR_REF(k3))
-            if (k2 < 0x7F800000u) RR_PUSH(RR_REF(k2))
-            if (k1 < 0x7F800000u) RR_PUSH(RR_REF(k1))
-            if (k0 < 0x7F800000u) { cur = RR_REF(k0); continue; }
-#undef RR_REF
+            const uint32_t k0 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST0), k1 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST1);
+            const uint32_t k2 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST2), k3 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST3);
+            // rank of my child among the four (0 = nearest); number of hit children of the quad
+            const int rank = (int)(k0 < mykey) + (int)(k1 < mykey) + (int)(k2 < mykey) + (int)(k3 < mykey);
+            const int nhit = __builtin_popcount((unsigned)(__ballot(h) >> qsh) & 0xFu);
+            // nearest child -> cur (OR-reduce over the quad); the others go on the stack far-first,
+            // each lane storing its OWN reference: no sorted copies of the refs are needed
+            uint32_t nxt = (h && rank == 0) ? myref : 0u;
+            nxt |= (uint32_t)RR_DPP_I(nxt, RR_QXOR1);
+            nxt |= (uint32_t)RR_DPP_I(nxt, RR_QXOR2);
+            if (h && rank > 0) {
+                const int e = sp + (nhit - 1 - rank);
+                if (SPILL && e >= stack_lds) spill[(size_t)(e - stack_lds) * spill_stride + gray] = myref;
+                else my[e * kRaysPerWave] = myref;
+            }
+            if (nhit > 0) { sp += nhit - 1; cur = nxt; continue; }
         } else {
             float t = __builtin_inff();
             uint32_t face = 0xFFFFFFFFu, tri = 0xFFFFFFFFu;
@@ -155,14 +158,13 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
         if (STATS) n_tris += 0x10000u;   // high half: loop iterations of this lane
         if (sp == 0) break;
         sp--;
-        cur = (sp < stack_lds) ? my[sp * kRaysPerWave] : spill[(size_t)(sp - stack_lds) * spill_stride + gray];
+        cur = (SPILL && sp >= stack_lds) ? spill[(size_t)(sp - stack_lds) * spill_stride + gray] : my[sp * kRaysPerWave];
     }
-#undef RR_PUSH
     return best;
 }
 
 // grid: (ceil(cap/64), n_seg), block 256 (= 64 rays), dynamic LDS = 4 waves * stack_lds * 16 * 4
-template <bool FIRST, bool STATS>
+template <bool FIRST, bool STATS, bool SPILL>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
 {
     extern __shared__ uint32_t lds_stack[];
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     const bool active = k < count;
     // pass 0 is traced in a spatially sorted order of the beam samples; results are
     // stored under the wave's own index j, so the reference order is untouched
-    const int j = (FIRST && active) ? (int)P.beam_order[k] : k;
+    int j = k;
+    if (active) j = FIRST ? (int)P.beam_order[k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
 
     V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
     if (active) {
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
         Hit h; h.t = 1.0f; h.tri = 0; h.face = 0;
         if (!(P.debug & 32))
-            h = traverse<STATS>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
+            h = traverse<STATS, SPILL>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
                                 P.spill, P.spill_stride, gray, nn, nt);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, c
     const V3 o = { origs[3 * i], origs[3 * i + 1], origs[3 * i + 2] };
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
-    const Hit h = traverse<false>(P.nodes, P.tris, o, d, P.range_max, lds_stack, P.stack_lds,
+    const Hit h = traverse<false, true>(P.nodes, P.tris, o, d, P.range_max, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
     if ((threadIdx.x & 3) == 0) {
         out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
         if (!last) {
             const int c = f & 1;
             const int pos = n_child + block_excl_scan(c, tot, lds);
-            if (c) { if (pos < P.cap) P.idx[nxt][(size_t)seg * P.cap + pos] = (uint32_t)s; else ovf = 1; }
+            if (c) { if (pos < P.cap) { P.idx[nxt][(size_t)seg * P.cap + pos] = (uint32_t)s; P.refpos[base2 + s] = (uint32_t)pos; } else { ovf = 1; P.refpos[base2 + s] = 0xFFFFFFFFu; } }
             n_child += tot;
         }
         const int g = sr.cell >= 0 ? 1 : 0;
@@ -489,6 +492,27 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
         n_sig += tot;
         block_excl_scan(hit, tot, lds);
         n_hit += tot;
+    }
+    // trace order of the next pass: children in the (spatially sorted) trace order of their
+    // parents, all reflections first, then all refractions -> neighbouring quads stay coherent
+    __syncthreads();
+    {
+        int placed = 0;
+        for (int type = 0; type < 2; type++) {
+            for (int b = 0; b < count; b += 256) {
+                const int k = b + threadIdx.x;
+                int c = 0; uint32_t rp = 0xFFFFFFFFu;
+                if (k < count) {
+                    const uint32_t j = FIRST ? P.beam_order[k] : P.torder[cur][(size_t)seg * P.cap + k];
+                    const size_t sl = base2 + 2 * (size_t)j + type;
+                    if (P.cflag[sl] & 1) { rp = P.refpos[sl]; c = rp != 0xFFFFFFFFu; }
+                }
+                int tot;
+                const int pos = placed + block_excl_scan(c, tot, lds);
+                if (c) P.torder[nxt][(size_t)seg * P.cap + pos] = rp;
+                placed += tot;
+            }
+        }
     }
     if (__syncthreads_or((int)ovf) && threadIdx.x == 0) atomicOr(&P.counters->overflow, 1u);
     if (threadIdx.x == 0) {
@@ -760,13 +784,16 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s)
     const int cap_p = pass == 0 ? P.n_beam : P.cap;
     dim3 grid((cap_p + kRaysPerBlock - 1) / kRaysPerBlock, P.n_seg), block(kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
+    const bool spill = P.spill_depth > 0;
+#define RR_LAUNCH_TRACE(F, S, X) hipLaunchKernelGGL((k_trace<F, S, X>), grid, block, lds, s, P, pass)
     if (pass == 0) {
-        if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, s, P, pass);
-        else       hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, s, P, pass);
+        if (stats) { if (spill) RR_LAUNCH_TRACE(true, true, true); else RR_LAUNCH_TRACE(true, true, false); }
+        else       { if (spill) RR_LAUNCH_TRACE(true, false, true); else RR_LAUNCH_TRACE(true, false, false); }
     } else {
-        if (stats) hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, s, P, pass);
-        else       hipLaunchKernelGGL((k_trace<false, false>), grid, block, lds, s, P, pass);
+        if (stats) { if (spill) RR_LAUNCH_TRACE(false, true, true); else RR_LAUNCH_TRACE(false, true, false); }
+        else       { if (spill) RR_LAUNCH_TRACE(false, false, true); else RR_LAUNCH_TRACE(false, false, false); }
     }
+#undef RR_LAUNCH_TRACE
 }
 
 void launch_shade(const Params& P, int pass, hipStream_t s)
