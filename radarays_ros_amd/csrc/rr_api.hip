@@ -555,8 +555,17 @@ int rr_simulate_columns_device(rr_ctx* c, const float pose[7], int az_begin, int
     int rc = check_ready(c); if (rc) return rc;
     if (!pose || !d_cols_u8) return fail(c, -3, "rr_simulate_columns_device: null pose/output");
     RR_HIP(c, hipSetDevice(c->device));
-    c->last_lane = 0;
-    return run_frame(c, c->lanes[0], pose, az_begin, az_end, d_cols_u8, d_cols_f32, stream ? (hipStream_t)stream : c->stream);
+    // rotate over the frame lanes so that calls issued on DIFFERENT streams (pipelined
+    // multi-GPU slots) can overlap; a lane is reused only after its previous frame finished
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t li = c->next_lane++ % c->lanes.size();
+    Lane& L = c->lanes[li];
+    c->last_lane = li;
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
+    rc = run_frame(c, L, pose, az_begin, az_end, d_cols_u8, d_cols_f32, s); if (rc) return rc;
+    RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+    L.pending_consume = true;
+    return 0;
 }
 
 int rr_assemble_image_device(rr_ctx* c, const uint8_t* d_cols_u8, uint8_t* d_img_u8, void* stream)
