@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--ambient-noise", type=int, default=2)
+    ap.add_argument("--force-slots", action="store_true", help="run the N>1 frame loop on one rank (debug)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,7 +81,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_slots:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -100,7 +104,8 @@ def main():
     ctx.set_noise_offsets(noise)
     n_tris = len(scene["faces"])
 
-    shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank))
+    shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank),
+                         force_slots=args.force_slots)
     stream = torch.cuda.current_stream()
 
     def step(k):
@@ -183,7 +188,7 @@ def main():
 
     shard.close()
     ctx.close()
-    if world > 1:
+    if world > 1 or args.force_slots:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -53,12 +53,13 @@ class _Slot:
 class AzimuthShard:
     """Frame loop of one rank: simulate my azimuth block, all-gather, assemble mono8."""
 
-    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3):
+    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3, force_slots=False):
         self.ctx, self.n_cells, self.n_angles = ctx, n_cells, n_angles
         self.rank, self.world, self.device = rank, world, device
         self.begin, self.end = partition(n_angles, world, rank)
         self.k = 0
-        if world == 1:
+        self.sharded = world > 1 or force_slots      # force_slots: exercise the N>1 path on one rank
+        if not self.sharded:
             self.image = torch.zeros((n_cells, n_angles), dtype=torch.uint8, device=device)
         else:
             self.slots = [_Slot(self.end - self.begin, n_cells, n_angles, device) for _ in range(n_slots)]
@@ -72,7 +73,7 @@ class AzimuthShard:
         overlap the all-gather of frame k).  Call `wait(stream)` before consuming;
         an image stays valid until `n_slots - 1` further frames have been enqueued."""
         stream = stream or torch.cuda.current_stream()
-        if self.world == 1:
+        if not self.sharded:
             # pipelining across frames happens inside the library (frame lanes)
             self.ctx.simulate_device(pose, self.image.data_ptr(), stream.cuda_stream)
             return self.image
@@ -89,7 +90,7 @@ class AzimuthShard:
 
     def wait(self, stream=None):
         """Make `stream` wait for the most recently enqueued frame (world > 1)."""
-        if self.world > 1 and getattr(self, "last", None) is not None:
+        if self.sharded and getattr(self, "last", None) is not None:
             (stream or torch.cuda.current_stream()).wait_event(self.last.done)
 
     def close(self):
