@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         Hit h; h.t = 1.0f; h.tri = 0; h.face = 0;
         if (!(P.debug & 32))
             h = traverse<STATS, SPILL>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
-                                P.spill, P.spill_stride, gray, nn, nt);
+                                       P.spill, P.spill_stride, gray, nn, nt);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
             P.hit_t[hk] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
