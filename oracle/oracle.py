@@ -83,6 +83,8 @@ def lib():
     L.orc_simulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                C.POINTER(OrcConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OrcStats)]
+    L.orc_simulate_motion.restype = C.c_int
+    L.orc_simulate_motion.argtypes = L.orc_simulate.argtypes
     L.orc_fresnel.argtypes = [fp, fp, C.c_double, C.c_double, C.c_double, C.c_double,
                               fp, C.POINTER(C.c_double), fp, C.POINTER(C.c_double)]
     L.orc_back_reflection_shader.restype = C.c_float
@@ -240,12 +242,13 @@ def simulate(scene, materials, object_materials, cfg, beam_dirs, pose, noise_rnd
     om = np.ascontiguousarray(object_materials, np.int32)
     bd = np.ascontiguousarray(beam_dirs, np.float32)
     ps = np.ascontiguousarray(pose, np.float32)
-    assert ps.shape == (7,)
+    motion = ps.ndim == 2          # include_motion: one pose per azimuth
+    assert ps.shape == ((n_angles, 7) if motion else (7,))
     nr = None if noise_rnd is None else np.ascontiguousarray(noise_rnd, np.float32)
     u8 = np.zeros((oc.n_cells, n_angles), np.uint8)
     f32 = np.zeros((oc.n_cells, n_angles), np.float32) if want_f32 else None
     st = OrcStats()
-    rc = L.orc_simulate(scene._h, mats, len(materials), om.ctypes.data, len(om), C.byref(oc),
+    rc = (L.orc_simulate_motion if motion else L.orc_simulate)(scene._h, mats, len(materials), om.ctypes.data, len(om), C.byref(oc),
                         bd.ctypes.data, len(bd), ps.ctypes.data,
                         None if nr is None else nr.ctypes.data,
                         az_begin, az_end, u8.ctypes.data,

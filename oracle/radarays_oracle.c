@@ -712,12 +712,12 @@ static double now_s(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-int orc_simulate(const orc_scene* scene,
+static int simulate_impl(const orc_scene* scene,
                  const orc_material* materials, size_t n_materials,
                  const int32_t* object_materials, size_t n_objects,
                  const orc_config* cfg,
                  const float* beam_dirs, size_t n_beam,
-                 const float pose[7],
+                 const float* pose, int pose_stride,
                  const float* noise_rnd,
                  int az_begin, int az_end,
                  uint8_t* out_u8, float* out_f32,
@@ -742,8 +742,6 @@ int orc_simulate(const orc_scene* scene,
         }
     }
 
-    const quat q_sm = { pose[0], pose[1], pose[2], pose[3] };
-    const v3 t_sm = { pose[4], pose[5], pose[6] };
     const float thr = cfg->wave_energy_threshold;
 
     uint64_t tot_wp = 0, tot_hits = 0, tot_sig = 0, tot_nodes = 0, tot_tris = 0;
@@ -775,6 +773,10 @@ int orc_simulate(const orc_scene* scene,
             wv_push(&waves, &wv);
         }
 
+        /* :190-196 include_motion: Tsm is looked up per azimuth (pose_stride = 7), else once (:127-134) */
+        const float* ps = pose + (size_t)pose_stride * (size_t)angle_id;
+        const quat q_sm = { ps[0], ps[1], ps[2], ps[3] };
+        const v3 t_sm = { ps[4], ps[5], ps[6] };
         /* :201-206  Tas.R = Euler(0,0,theta(angle_id)), Tas.t = 0; Tam = Tsm * Tas */
         const float theta = cfg->theta_min + (float)angle_id * cfg->theta_inc;
         const quat q_as = q_from_euler(0.0f, 0.0f, theta);
@@ -966,4 +968,36 @@ int orc_simulate(const orc_scene* scene,
         stats->seconds = t_stop - t_start;
     }
     return err ? -10 - err : 0;
+}
+
+int orc_simulate(const orc_scene* scene,
+                 const orc_material* materials, size_t n_materials,
+                 const int32_t* object_materials, size_t n_objects,
+                 const orc_config* cfg,
+                 const float* beam_dirs, size_t n_beam,
+                 const float pose[7],
+                 const float* noise_rnd,
+                 int az_begin, int az_end,
+                 uint8_t* out_u8, float* out_f32,
+                 int n_threads, orc_stats* stats)
+{
+    return simulate_impl(scene, materials, n_materials, object_materials, n_objects, cfg, beam_dirs, n_beam,
+                         pose, 0, noise_rnd, az_begin, az_end, out_u8, out_f32, n_threads, stats);
+}
+
+/* include_motion = true (RadarCPU.cpp:190-196): one Tsm per azimuth, poses[n_angles][7].
+ * (The reference serialises this mode only because of ros::spinOnce, :544-547.) */
+int orc_simulate_motion(const orc_scene* scene,
+                 const orc_material* materials, size_t n_materials,
+                 const int32_t* object_materials, size_t n_objects,
+                 const orc_config* cfg,
+                 const float* beam_dirs, size_t n_beam,
+                 const float* poses,
+                 const float* noise_rnd,
+                 int az_begin, int az_end,
+                 uint8_t* out_u8, float* out_f32,
+                 int n_threads, orc_stats* stats)
+{
+    return simulate_impl(scene, materials, n_materials, object_materials, n_objects, cfg, beam_dirs, n_beam,
+                         poses, 7, noise_rnd, az_begin, az_end, out_u8, out_f32, n_threads, stats);
 }

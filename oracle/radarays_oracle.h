@@ -117,6 +117,18 @@ int orc_simulate(const orc_scene*,
                  uint8_t* out_u8, float* out_f32,
                  int n_threads, orc_stats* stats);
 
+/* include_motion = true (RadarCPU.cpp:190-196): poses[n_angles][7], one Tsm per azimuth. */
+int orc_simulate_motion(const orc_scene*,
+                 const orc_material* materials, size_t n_materials,
+                 const int32_t* object_materials, size_t n_objects,
+                 const orc_config* cfg,
+                 const float* beam_dirs, size_t n_beam,
+                 const float* poses,
+                 const float* noise_rnd,
+                 int az_begin, int az_end,
+                 uint8_t* out_u8, float* out_f32,
+                 int n_threads, orc_stats* stats);
+
 /* ---- per-hit math, exported one by one for the known-answer tests ---- */
 
 /* radar_algorithms.h:55-139.  in: normal, incidence dir, energy, polarization,

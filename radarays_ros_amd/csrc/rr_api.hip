@@ -91,13 +91,14 @@ struct rr_ctx {
     bool have_materials = false;
     std::vector<float> beams;   // xyz
     std::vector<float> noise;
+    std::vector<float> motion;   // [n_angles][7] or empty
     std::vector<float> smear;
     int smear_mode = 0;
 
     DevBuf<float4> d_qas, d_beams, d_materials;
     DevBuf<uint32_t> d_beam_order;
     DevBuf<int32_t> d_objmat;
-    DevBuf<float> d_smear, d_noise;
+    DevBuf<float> d_smear, d_noise, d_motion;
     bool tables_dirty = true;
 
     // frame lanes: each owns a full set of frame buffers + a stream, so consecutive
@@ -253,6 +254,11 @@ int upload_tables(rr_ctx* c)
     for (size_t i = 0; i < nz.size() && i < c->noise.size(); i++) nz[i] = c->noise[i];
     RR_HIP(c, c->d_noise.ensure(nz.size()));
     RR_HIP(c, hipMemcpy(c->d_noise.p, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!c->motion.empty()) {
+        if (c->motion.size() != 7 * (size_t)g.n_angles) return fail(c, -3, "rr_set_motion_poses: need n_angles poses");
+        RR_HIP(c, c->d_motion.ensure(c->motion.size()));
+        RR_HIP(c, hipMemcpy(c->d_motion.p, c->motion.data(), c->motion.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     c->tables_dirty = false;
     return 0;
 }
@@ -308,6 +314,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.materials = c->d_materials.p;
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
+    P.motion_poses = c->motion.empty() ? nullptr : c->d_motion.p;
     for (int k = 0; k < 2; k++) {
         P.waves[k].A = L.d_wA[k].p; P.waves[k].B = L.d_wB[k].p; P.waves[k].C = L.d_wC[k].p;
         P.idx[k] = L.d_idx[k].p; P.count[k] = L.d_count[k].p; P.torder[k] = L.d_torder[k].p;
@@ -456,7 +463,7 @@ void rr_destroy(rr_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
-    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_beam_order.release();
+    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_beam_order.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
@@ -545,6 +552,16 @@ int rr_set_noise_offsets(rr_ctx* c, const float* rnd, size_t n)
     if (!c) return -1;
     if (n && !rnd) return fail(c, -3, "rr_set_noise_offsets: null pointer");
     c->noise.assign(rnd, rnd + n);
+    c->tables_dirty = true;
+    return 0;
+}
+
+int rr_set_motion_poses(rr_ctx* c, const float* poses, size_t n)
+{
+    if (!c) return -1;
+    if (n && !poses) return fail(c, -3, "rr_set_motion_poses: null pointer");
+    for (size_t i = 0; i < 7 * n; i++) if (!std::isfinite(poses[i])) return fail(c, -3, "rr_set_motion_poses: non-finite pose");
+    c->motion.assign(poses, poses + 7 * n);
     c->tables_dirty = true;
     return 0;
 }

@@ -25,9 +25,14 @@ __device__ inline Quat ld_quat(const float4* p) { const float4 v = *p; return { 
 __device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t_am)
 {
     const Quat q_as = ld_quat(P.q_as + (P.az_begin + seg));
-    q_am = q_mul(P.q_sm, q_as);
+    Quat q_sm = P.q_sm; V3 t_sm = P.t_sm;
+    if (P.motion_poses) {     // include_motion: Tsm looked up per azimuth (RadarCPU.cpp:190-196)
+        const float* ps = P.motion_poses + 7 * (size_t)(P.az_begin + seg);
+        q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
+    }
+    q_am = q_mul(q_sm, q_as);
     const V3 zero = { 0.0f, 0.0f, 0.0f };
-    t_am = v_add(q_rot(P.q_sm, zero), P.t_sm);
+    t_am = v_add(q_rot(q_sm, zero), t_sm);
 }
 
 struct Hit { float t; uint32_t tri; uint32_t face; };

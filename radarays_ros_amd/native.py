@@ -16,7 +16,7 @@ _LIB = None
 SYMBOLS = [
     "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
     "rr_set_mesh", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
-    "rr_set_noise_offsets", "rr_simulate", "rr_simulate_columns_device",
+    "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device",
     "rr_assemble_image_device", "rr_simulate_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
     "rr_get_kernel_time",
@@ -97,6 +97,7 @@ def lib():
     L.rr_set_config.argtypes = [vp, C.POINTER(RRConfig)]
     L.rr_set_beam_samples.argtypes = [vp, vp, C.c_size_t]
     L.rr_set_noise_offsets.argtypes = [vp, vp, C.c_size_t]
+    L.rr_set_motion_poses.argtypes = [vp, vp, C.c_size_t]
     L.rr_simulate.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(RRStats)]
     L.rr_simulate_columns_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.rr_assemble_image_device.argtypes = [vp, vp, vp, vp]
@@ -206,6 +207,14 @@ class Context:
     def set_noise_offsets(self, rnd):
         r = np.ascontiguousarray(rnd, np.float32)
         self._ck(self._L.rr_set_noise_offsets(self._h, r.ctypes.data, len(r)))
+
+    def set_motion_poses(self, poses):
+        """include_motion: [n_angles][7] per-azimuth poses; None/empty switches it off."""
+        if poses is None or len(poses) == 0:
+            self._ck(self._L.rr_set_motion_poses(self._h, None, 0))
+            return
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ck(self._L.rr_set_motion_poses(self._h, p.ctypes.data, len(p)))
 
     def simulate(self, pose, az_begin=0, az_end=None, want_f32=False):
         """Host-buffer path (rr_simulate). Returns (u8 [n_cells][n_angles], f32|None, stats)."""

@@ -101,6 +101,14 @@ class RadarHIP:
         self.m_resample = False
         self._ctx.set_beam_samples(self.m_waves_start)
 
+    def setMotionPoses(self, poses):
+        """include_motion (cfg/RadarModel.cfg:85): the pose TF would return at each azimuth
+        (RadarCPU.cpp:190-196), [400][7]; None -> one pose per frame."""
+        self._motion = None if poses is None else np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ctx.set_motion_poses(self._motion)
+        if self._motion is not None:
+            self.Tsm_last = self._motion[-1].copy()
+
     def setNoiseOffsets(self, rnd):
         self._ctx.set_noise_offsets(rnd)
 

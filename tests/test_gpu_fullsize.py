@@ -1,0 +1,84 @@
+"""BASELINE.json's full sizes (configs[2..3] scale: 10M triangles, 200 / 1000 rays, 4 passes)
+through size-independent properties + an oracle spot check on a few azimuths."""
+import numpy as np
+import pytest
+
+from common import golden_beams, image_diff, materials_for, mats_tuple
+from radarays_ros_amd import params, scenes
+from radarays_ros_amd.dist import partition
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(native_lib):
+    s = scenes.config_scene(4)                     # 10,248,350 triangles
+    c = native_lib.Context(0)
+    c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    c.set_materials(materials_for(s), s["object_materials"], 0)
+    yield s, c
+    c.close()
+
+
+def test_target_config_properties(big, native_lib):
+    s, c = big
+    cfg = params.kaist_preset(n_reflections=4, ambient_noise=0)
+    c.set_config(cfg)
+    c.set_beam_samples(golden_beams(200))
+    pose = scenes.default_pose(s["name"])
+    info = c.bvh_info()
+    assert info["n_tris"] == len(s["faces"]) == 10248350
+    full, _, st = c.simulate(pose)
+    assert st["overflow"] == 0
+    # closed scene: every pass-0 wave hits; counts are ordered
+    assert st["wave_passes"] >= 80000 and st["hits"] <= st["wave_passes"] and st["signals"] <= st["hits"]
+    assert st["hits"] > 0.99 * st["wave_passes"]
+    # normalisation: every column peaks at round(energy_max * signal_max) = 79 (Appendix A.8)
+    assert np.all(full.max(axis=0) == 79)
+    # bin 0 is never written (RadarCPU.cpp:424)
+    assert not full[0].any()
+    # determinism (no atomics in the image path)
+    again, _, st2 = c.simulate(pose)
+    assert np.array_equal(full, again) and st2 == st
+    # azimuth sharding as 8 ranks would do it == the full frame
+    parts = np.zeros_like(full)
+    wp = 0
+    for r in range(8):
+        b, e = partition(400, 8, r)
+        p, _, sr = c.simulate(pose, b, e)
+        parts[:, b:e] = p[:, b:e]
+        wp += sr["wave_passes"]
+    assert np.array_equal(full, parts) and wp == st["wave_passes"]
+    # scroll_image only rotates columns
+    c.set_config(cfg.copy(scroll_image=123))
+    rolled, _, _ = c.simulate(pose)
+    assert np.array_equal(np.roll(full, 123, axis=1), rolled)
+
+
+def test_target_config_oracle_spot_check(big, native_lib, oracle):
+    s, c = big
+    cfg = params.kaist_preset(n_reflections=4, ambient_noise=0)
+    c.set_config(cfg)
+    c.set_beam_samples(golden_beams(200))
+    pose = scenes.default_pose(s["name"])
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=1)
+    for az in ((37, 39), (250, 252)):
+        g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
+        o8, of, ost = oracle.simulate(sc, mats_tuple(materials_for(s)), s["object_materials"], cfg,
+                                      golden_beams(200), pose, az_begin=az[0], az_end=az[1])
+        assert gst["wave_passes"] == ost["wave_passes"] and gst["signals"] == ost["signals"]
+        d = image_diff(gf[:, az[0]:az[1]], of[:, az[0]:az[1]], g8[:, az[0]:az[1]], o8[:, az[0]:az[1]])
+        assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1, d
+
+
+def test_config4_1000_rays(big, native_lib):
+    s, c = big
+    cfg = params.kaist_preset(n_reflections=4, ambient_noise=2)
+    c.set_config(cfg)
+    c.set_beam_samples(golden_beams(1000))
+    c.set_noise_offsets((np.random.RandomState(7).uniform(0, 1, 400) * 1000).astype(np.float32))
+    img, _, st = c.simulate(scenes.default_pose(s["name"]))
+    assert st["overflow"] == 0 and st["wave_passes"] >= 400000 and st["hits"] > 0.99 * st["wave_passes"]
+    assert img.max() <= 255 and (img > 0).mean() > 0.5      # noise floor fills the image
+    again, _, _ = c.simulate(scenes.default_pose(s["name"]))
+    assert np.array_equal(img, again)

@@ -143,6 +143,29 @@ def test_config3_subset_1m_tris_4_passes(native_lib, oracle):
         _check(native_lib, oracle, s, cfg, materials_for(s), golden_beams(200), scenes.default_pose(s["name"]), az)
 
 
+def test_include_motion_per_azimuth_poses(native_lib, oracle):
+    """include_motion = true: one Tsm per azimuth (RadarCPU.cpp:190-196)."""
+    s = gen.two_room_scene()
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=0, include_motion=True)
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    a = np.linspace(0.0, 1.0, 400)
+    poses = np.stack([scenes.yaw_pose(1.0 + 2.0 * t, 1.5 - 1.0 * t, 0.2 + 0.5 * t, 0.3 + 0.4 * t) for t in a])
+    c = _ctx(native_lib, s, cfg, mats, golden_beams(32))
+    c.set_motion_poses(poses)
+    g8, gf, gst = c.simulate(poses[0], want_f32=True)
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
+    o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, golden_beams(32), poses)
+    assert gst["wave_passes"] == ost["wave_passes"] and gst["signals"] == ost["signals"]
+    d = image_diff(gf, of, g8, o8)
+    assert d["mean_dev"] <= MEAN_DEV_TOL and d["u8_max"] <= 1, d
+    # switching it off again gives the static-pose frame
+    c.set_motion_poses(None)
+    s8, _, _ = c.simulate(poses[0])
+    r8, _, _ = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, golden_beams(32), poses[0])
+    assert np.abs(s8.astype(int) - r8.astype(int)).max() <= 1 and not np.array_equal(s8, g8)
+    c.close()
+
+
 def test_azimuth_sharding_is_exact(native_lib):
     """Columns are independent: blocks computed separately == full frame."""
     s = gen.two_room_scene()
