@@ -12,8 +12,11 @@ parameters and beam samples are resident in HBM before the timed region; poses a
 floats passed as kernel arguments; the image stays in HBM.
 
 N > 1 (north_star): the 400 azimuth columns of EVERY frame are sharded over the ranks
-(400/N columns each), one RCCL all-gather over xGMI assembles the frame on every rank
--> total work per step is fixed: "scaling": "strong".
+(400/N columns each) and assembled by ONE RCCL collective over xGMI per step
+(default, "scaling": "weak"): a step renders N frames; rank r simulates its 400/N-column
+block of all N frames in one set of launches and ONE all_to_all_single (the N per-frame
+gathers fused) hands frame f to rank f -- per-GPU work per step is constant, value = N*K/t.
+`--strong`: one frame per step + one all-gather (latency mode).
 
 Extra objects on the JSON line: "roofline" (dominant kernel = k_trace, hipEvent-timed on
 its launch stream inside the timed region) and, at N = 1 on rank 0, "cpu_baseline" (the
@@ -61,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--ambient-noise", type=int, default=2)
+    ap.add_argument("--strong", action="store_true", help="N>1: one frame per step + all-gather")
     ap.add_argument("--force-slots", action="store_true", help="run the N>1 frame loop on one rank (debug)")
     args = ap.parse_args()
 
@@ -105,17 +109,18 @@ def main():
     n_tris = len(scene["faces"])
 
     shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank),
-                         force_slots=args.force_slots)
+                         force_slots=args.force_slots, strong=args.strong)
+    fps = shard.frames_per_step
     stream = torch.cuda.current_stream()
 
     def step(k):
-        shard.frame(poses[k % len(poses)], stream)
+        shard.step([poses[(k * fps + f) % len(poses)] for f in range(fps)], stream)
 
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
     # one instrumented frame outside the timed region: wave-pass count of this workload
-    shard.frame(poses[0], stream)
+    step(0)
     torch.cuda.synchronize()
     st = ctx.stats()
     wave_passes_frame_rank = st["wave_passes"]
@@ -149,11 +154,11 @@ def main():
 
     out = None
     if rank == 0:
-        img_per_s = args.steps / elapsed
+        img_per_s = args.steps * fps / elapsed
         b_wp = algorithmic_bytes_per_wave_pass(n_tris)
         launches_per_frame = max(1, n_pass)
         avg_trace_s = (trace_ms / max(trace_launches, 1)) * 1e-3
-        bytes_per_launch = wave_passes_frame_rank / launches_per_frame * b_wp
+        bytes_per_launch = wave_passes_frame_rank / launches_per_frame * b_wp      # one step of this rank
         achieved = bytes_per_launch / avg_trace_s / 1e9 if avg_trace_s > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -166,16 +171,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if (world > 1 and args.strong) else "weak",
             "vs_baseline": None,
             "dtype": "f32 rays / f64 energy+time",
             "data": "synthetic",
             "config": {"workload": args.workload, "triangles": int(n_tris), "azimuths": params.N_ANGLES,
                        "range_bins": int(cfg.n_cells), "rays_per_beam": n_rays, "passes": n_pass,
                        "ambient_noise": int(cfg.ambient_noise),
-                       "sharding": "azimuth columns x%d + 1 RCCL all-gather/frame" % world if world > 1 else "single GPU"},
-            "rays_per_s": round(wave_passes_frame * img_per_s, 1),
-            "wave_passes_per_frame": int(wave_passes_frame),
+                       "frames_per_step": fps,
+                       "sharding": ("single GPU" if world == 1 else
+                                    "azimuth columns x%d, 1 frame/step + 1 all-gather" % world if args.strong else
+                                    "azimuth columns x%d, %d frames/step, 1 all_to_all/step (frame f -> rank f)" % (world, fps))},
+            "rays_per_s": round(wave_passes_frame / fps * img_per_s, 1),
+            "wave_passes_per_frame": int(wave_passes_frame // fps),
             "roofline": {"bound": "hbm", "kernel": "k_trace",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

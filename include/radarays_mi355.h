@@ -143,6 +143,14 @@ int rr_simulate(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_begin, int az_e
 int rr_simulate_columns_device(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_begin, int az_end,
                                uint8_t* d_cols_u8, float* d_cols_f32, void* stream);
 
+/* Frame batch (multi-GPU weak scaling, offline generation): the same azimuth block
+ * [az_begin, az_end) of n_frames (1..8) different poses in ONE set of launches.
+ * poses = [n_frames][7]; d_cols_u8 = [n_frames][az_end-az_begin][n_cells].  Kernels then see
+ * n_frames x block segments, i.e. a rank that owns 1/N of the azimuths of N frames does the
+ * same amount of work per launch as a single GPU does for one whole frame. */
+int rr_simulate_batch_columns_device(rr_ctx* ctx, const float* poses, int n_frames, int az_begin, int az_end,
+                                     uint8_t* d_cols_u8, void* stream);
+
 /* Assemble the mono8 image from column-major columns, applying scroll_image
  * (RadarCPU.cpp:457): d_img[c][(scroll + a) % n_angles] = d_cols[a][c].
  * Device buffers, asynchronous on `stream`. */

@@ -369,14 +369,16 @@ int check_ready(rr_ctx* c)
     return 0;
 }
 
-int run_frame(rr_ctx* c, Lane& L, const float pose[7], int az_begin, int az_end,
-              uint8_t* d_cols_u8, float* d_cols_f32, hipStream_t s)
+int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
+              uint8_t* d_cols_u8, float* d_cols_f32, hipStream_t s, int n_frames = 1)
 {
     const rr_config& g = c->cfg;
     if (az_begin < 0 || az_end > g.n_angles || az_begin > az_end) return fail(c, -3, "azimuth range out of bounds");
-    const int n_seg = az_end - az_begin;
+    const int n_loc = az_end - az_begin;
+    const int n_seg = n_loc * n_frames;
     if (n_seg == 0) return 0;
-    for (int k = 0; k < 7; k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
+    if (n_frames < 1 || n_frames > 8) return fail(c, -3, "frame batch must be 1..8");
+    for (int k = 0; k < 7 * n_frames; k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
     int rc = upload_tables(c); if (rc) return rc;
     const int n_beam = (int)(c->beams.size() / 3);
     const int cap = wave_capacity(g, n_beam);
@@ -386,6 +388,8 @@ int run_frame(rr_ctx* c, Lane& L, const float pose[7], int az_begin, int az_end,
     }
     Params P;
     fill_params(c, L, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
+    P.n_loc = n_loc; P.n_frames = n_frames;
+    for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[7 * f + k];
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
     L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
     for (int pass = 0; pass < g.n_reflections; pass++) {
@@ -580,6 +584,23 @@ int rr_simulate_columns_device(rr_ctx* c, const float pose[7], int az_begin, int
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     rc = run_frame(c, L, pose, az_begin, az_end, d_cols_u8, d_cols_f32, s); if (rc) return rc;
+    RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+    L.pending_consume = true;
+    return 0;
+}
+
+int rr_simulate_batch_columns_device(rr_ctx* c, const float* poses, int n_frames, int az_begin, int az_end,
+                                     uint8_t* d_cols_u8, void* stream)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!poses || !d_cols_u8) return fail(c, -3, "rr_simulate_batch_columns_device: null poses/output");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t li = c->next_lane++ % c->lanes.size();
+    Lane& L = c->lanes[li];
+    c->last_lane = li;
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
+    rc = run_frame(c, L, poses, az_begin, az_end, d_cols_u8, nullptr, s, n_frames); if (rc) return rc;
     RR_HIP(c, hipEventRecord(L.ev_consumed, s));
     L.pending_consume = true;
     return 0;

@@ -108,6 +108,10 @@ struct Params {
     // scalars
     Quat q_sm; V3 t_sm;
     int az_begin, n_seg;
+    // frame batch: segment s belongs to frame s / n_loc and azimuth az_begin + s % n_loc;
+    // frame f > 0 uses batch_poses[f - 1] (frame 0 uses q_sm / t_sm)
+    int n_loc, n_frames;
+    float batch_poses[7][7];
     int n_beam, cap, sigcap;
     int n_cells, n_angles, n_materials, n_objects, material_id_air;
     int n_passes, record_multi_reflection, record_multi_path;

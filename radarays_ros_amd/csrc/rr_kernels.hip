@@ -24,10 +24,15 @@ __device__ inline Quat ld_quat(const float4* p) { const float4 v = *p; return { 
 // Tam = Tsm * Tas (RadarCPU.cpp:201-206); Tas.t = 0.
 __device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t_am)
 {
-    const Quat q_as = ld_quat(P.q_as + (P.az_begin + seg));
+    const int frame = seg / P.n_loc, az = P.az_begin + seg % P.n_loc;
+    const Quat q_as = ld_quat(P.q_as + az);
     Quat q_sm = P.q_sm; V3 t_sm = P.t_sm;
+    if (frame > 0) {          // frame batch: one pose per frame, passed by value
+        const float* ps = P.batch_poses[frame - 1];
+        q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
+    }
     if (P.motion_poses) {     // include_motion: Tsm looked up per azimuth (RadarCPU.cpp:190-196)
-        const float* ps = P.motion_poses + 7 * (size_t)(P.az_begin + seg);
+        const float* ps = P.motion_poses + 7 * (size_t)az;
         q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
     }
     q_am = q_mul(q_sm, q_as);
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     float max_val = 0.0f;
     for (int k = 0; k < kColWaves; k++) max_val = fmaxf(max_val, s_red[k]);
 
-    const int angle_id = P.az_begin + seg;
+    const int angle_id = P.az_begin + seg % P.n_loc;
     const int col = (P.scroll + angle_id) % P.n_angles;   // :457 (placement is done by the assemble step)
     const float final_scale = (float)(P.signal_max / (double)max_val);   // :533
     const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[angle_id] : 0.0f;

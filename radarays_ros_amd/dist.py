@@ -1,16 +1,23 @@
 """Multi-GPU: azimuth columns are independent (RadarCPU.cpp:155 runs them under
-`#pragma omp parallel for`), so a frame shards over ranks by contiguous azimuth
-blocks; ONE RCCL all-gather over xGMI per frame assembles the columns (no
-reduction: blocks are disjoint).  The reference has no distributed code at all
-(SURVEY.md §5); this is the MI355X design of BASELINE.json:north_star.
+`#pragma omp parallel for`), so frames shard over ranks by contiguous azimuth
+blocks and ONE RCCL collective over xGMI per step assembles them (no reduction:
+blocks are disjoint).  The reference has no distributed code at all;
+this is the MI355X design of BASELINE.json:north_star.
 
-One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm).  torch
-is plumbing here: device buffers, streams, the collective.
+Default (weak scaling): a step renders `world` frames.  Rank r simulates ITS azimuth
+block of all `world` frames in one set of launches (rr_simulate_batch_columns_device:
+world x 400/world = 400 segments, the same launch shape as one whole frame on one
+GPU), then the per-frame gathers "columns of frame f -> rank f" are fused into a
+single `all_to_all_single`; rank r assembles frame r.  Per-GPU work per step is
+constant, each rank receives one frame (1.37 MB) per step.
 
-Frames are pipelined over a few slots (own HIP stream + own column/image
-buffers): the all-gather of frame k runs on RCCL's stream while the kernels of
-frame k+1 already execute -- the collective is latency-, not bandwidth-bound
-(1.37 MB per frame over 7 xGMI links), so hiding it is what matters.
+`strong=True`: one frame per step sharded over all ranks + one all-gather (every
+rank gets the frame) -- the latency mode for heavy frames (config 4).
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm).  torch is
+plumbing here: device buffers, streams, the collective.  Steps are pipelined over a
+few slots (own HIP stream + buffers) so the collective of step k overlaps the
+kernels of step k+1.
 """
 import torch
 import torch.distributed as dist
@@ -42,54 +49,71 @@ def gather_columns(cols_block, n_angles, world, group=None, out=None):
 
 
 class _Slot:
-    def __init__(self, n_local, n_cells, n_angles, device):
+    def __init__(self, n_frames, n_local, n_cells, n_angles, device):
         self.stream = torch.cuda.Stream(device=device)
-        self.block = torch.zeros((n_local, n_cells), dtype=torch.uint8, device=device)
+        self.block = torch.zeros((n_frames, n_local, n_cells), dtype=torch.uint8, device=device)
         self.cols = torch.zeros((n_angles, n_cells), dtype=torch.uint8, device=device)
         self.image = torch.zeros((n_cells, n_angles), dtype=torch.uint8, device=device)
         self.done = torch.cuda.Event()
 
 
 class AzimuthShard:
-    """Frame loop of one rank: simulate my azimuth block, all-gather, assemble mono8."""
+    """Step loop of one rank (see module docstring)."""
 
-    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3, force_slots=False):
+    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3, force_slots=False, strong=False):
         self.ctx, self.n_cells, self.n_angles = ctx, n_cells, n_angles
         self.rank, self.world, self.device = rank, world, device
         self.begin, self.end = partition(n_angles, world, rank)
         self.k = 0
         self.sharded = world > 1 or force_slots      # force_slots: exercise the N>1 path on one rank
+        self.strong = strong or (n_angles % world != 0)
+        self.frames_per_step = 1 if (not self.sharded or self.strong) else world
         if not self.sharded:
             self.image = torch.zeros((n_cells, n_angles), dtype=torch.uint8, device=device)
         else:
-            self.slots = [_Slot(self.end - self.begin, n_cells, n_angles, device) for _ in range(n_slots)]
+            self.slots = [_Slot(self.frames_per_step, self.end - self.begin, n_cells, n_angles, device)
+                          for _ in range(n_slots)]
 
     def frame(self, pose, stream=None):
-        """Enqueue one frame and return the HBM tensor that will hold its mono8 image.
+        """Single-frame entry (world == 1, or strong sharding): see step()."""
+        return self.step([pose], stream)
+
+    def step(self, poses, stream=None):
+        """Enqueue one step = `frames_per_step` frames (poses: that many 7-float poses, the
+        same list on every rank) and return the HBM tensor that will hold THIS rank's mono8
+        image (weak mode: frame number `rank` of the step; otherwise the one frame).
 
         world == 1: ordered on `stream` (default: current stream).
-        world  > 1: asynchronous producer -- the frame runs on one of `n_slots` slot
-        streams and NEVER waits on the caller's stream (that is what lets frame k+1
-        overlap the all-gather of frame k).  Call `wait(stream)` before consuming;
-        an image stays valid until `n_slots - 1` further frames have been enqueued."""
+        sharded  : asynchronous producer -- the step runs on one of `n_slots` slot streams and
+        NEVER waits on the caller's stream (that is what lets step k+1 overlap the collective
+        of step k).  Call `wait(stream)` before consuming; an image stays valid until
+        `n_slots - 1` further steps have been enqueued."""
+        assert len(poses) == self.frames_per_step
         stream = stream or torch.cuda.current_stream()
         if not self.sharded:
             # pipelining across frames happens inside the library (frame lanes)
-            self.ctx.simulate_device(pose, self.image.data_ptr(), stream.cuda_stream)
+            self.ctx.simulate_device(poses[0], self.image.data_ptr(), stream.cuda_stream)
             return self.image
         s = self.slots[self.k % len(self.slots)]
         self.k += 1
         with torch.cuda.stream(s.stream):
             sp = s.stream.cuda_stream
-            self.ctx.simulate_columns_device(pose, self.begin, self.end, s.block.data_ptr(), None, sp)
-            cols = gather_columns(s.block, self.n_angles, self.world, out=s.cols)
+            if self.strong:
+                self.ctx.simulate_columns_device(poses[0], self.begin, self.end, s.block.data_ptr(), None, sp)
+                cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.cols)
+            else:
+                self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
+                # frame f's columns go to rank f; I receive every rank's block of frame `rank`,
+                # in rank order == azimuth order
+                dist.all_to_all_single(s.cols.view(-1), s.block.view(-1))
+                cols = s.cols
             self.ctx.assemble_image_device(cols.data_ptr(), s.image.data_ptr(), sp)
             s.done.record(s.stream)
         self.last = s
         return s.image
 
     def wait(self, stream=None):
-        """Make `stream` wait for the most recently enqueued frame (world > 1)."""
+        """Make `stream` wait for the most recently enqueued step (sharded mode)."""
         if self.sharded and getattr(self, "last", None) is not None:
             (stream or torch.cuda.current_stream()).wait_event(self.last.done)
 

@@ -16,7 +16,7 @@ _LIB = None
 SYMBOLS = [
     "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
     "rr_set_mesh", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
-    "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device",
+    "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device", "rr_simulate_batch_columns_device",
     "rr_assemble_image_device", "rr_simulate_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
     "rr_get_kernel_time",
@@ -100,6 +100,7 @@ def lib():
     L.rr_set_motion_poses.argtypes = [vp, vp, C.c_size_t]
     L.rr_simulate.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(RRStats)]
     L.rr_simulate_columns_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.rr_simulate_batch_columns_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.rr_assemble_image_device.argtypes = [vp, vp, vp, vp]
     L.rr_simulate_device.argtypes = [vp, vp, vp, vp]
     L.rr_synchronize.argtypes = [vp, vp]
@@ -234,6 +235,11 @@ class Context:
         p = np.ascontiguousarray(pose, np.float32)
         self._ck(self._L.rr_simulate_columns_device(self._h, p.ctypes.data, az_begin, az_end,
                                                     d_cols_u8_ptr, d_cols_f32_ptr, stream))
+
+    def simulate_batch_columns_device(self, poses, az_begin, az_end, d_cols_u8_ptr, stream=None):
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ck(self._L.rr_simulate_batch_columns_device(self._h, p.ctypes.data, len(p), az_begin, az_end,
+                                                          d_cols_u8_ptr, stream))
 
     def assemble_image_device(self, d_cols_u8_ptr, d_img_ptr, stream=None):
         self._ck(self._L.rr_assemble_image_device(self._h, d_cols_u8_ptr, d_img_ptr, stream))

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from radarays_ros_amd.dist import gather_columns, partition
+from radarays_ros_amd.dist import gather_columns, partition  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -76,3 +76,45 @@ def test_two_rank_gather_assembles_the_frame(tmp_path, oracle, n_angles, scroll)
     port = _free_port()
     mp.spawn(_worker, args=(2, port, n_angles, scroll, str(tmp_path)), nprocs=2, join=True)
     assert np.load(os.path.join(str(tmp_path), "ok.npy"))[0] == 1
+
+
+def _worker_weak(rank, world, port, n_angles, out_dir):
+    """Weak-scaling step: `world` frames, my azimuth block of each, ONE all_to_all_single,
+    I assemble frame number `rank` (the layout contract of AzimuthShard.step)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from radarays_ros_amd import params, scenes
+    from common import golden_beams, mats_tuple
+    import gen_oracle_images as gen
+    s = gen.two_room_scene()
+    cfg = params.kaist_preset(n_reflections=2, ambient_noise=0, n_cells=512, resolution=0.1)
+    sc = O.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
+    mats = mats_tuple(params.kaist_materials() + [params.PENETRABLE])
+    poses = scenes.trajectory(world, "box12")
+    b, e = partition(n_angles, world, rank)
+    blocks = []
+    for f in range(world):          # what rr_simulate_batch_columns_device writes: [frame][n_local][n_cells]
+        u8, _, _ = O.simulate(sc, mats, s["object_materials"], cfg, golden_beams(8), poses[f],
+                              az_begin=b, az_end=e, n_angles=n_angles, n_threads=1)
+        blocks.append(np.ascontiguousarray(u8[:, b:e].T))
+    block = torch.from_numpy(np.stack(blocks))
+    cols = torch.empty((n_angles, cfg.n_cells), dtype=torch.uint8)
+    dist.all_to_all_single(cols.view(-1), block.view(-1))
+    img = cols.t().contiguous().numpy()
+    full, _, _ = O.simulate(sc, mats, s["object_materials"], cfg, golden_beams(8), poses[rank],
+                            n_angles=n_angles, n_threads=1)
+    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([int(np.array_equal(img, full))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_weak_step_all_to_all(tmp_path, oracle):
+    port = _free_port()
+    mp.spawn(_worker_weak, args=(2, port, 40, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))[0] == 1

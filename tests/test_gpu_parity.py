@@ -280,6 +280,7 @@ def test_sharded_slot_path_on_one_rank(native_lib):
         dev = torch.device("cuda", 0)
         sh = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, n_slots=3, force_slots=True)
         got = []
+        assert sh.frames_per_step == 1
         for i, p in enumerate(poses):
             img = sh.frame(p)
             sh.wait()
@@ -296,3 +297,25 @@ def test_sharded_slot_path_on_one_rank(native_lib):
     finally:
         dist.destroy_process_group()
         c.close()
+
+
+def test_frame_batch_equals_single_frames(native_lib):
+    """rr_simulate_batch_columns_device: the same azimuth block of several poses in one set of
+    launches == the frames computed one by one (the multi-GPU weak-scaling step)."""
+    import torch
+    s = gen.two_room_scene()
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=2)
+    c = _ctx(native_lib, s, cfg, params.kaist_materials() + [params.PENETRABLE], golden_beams(32),
+             noise=(np.random.RandomState(5).uniform(0, 1, 400) * 1000).astype(np.float32))
+    poses = scenes.trajectory(5, "box12")
+    b, e = 100, 150
+    st = torch.cuda.current_stream().cuda_stream
+    block = torch.zeros((5, e - b, cfg.n_cells), dtype=torch.uint8, device="cuda:0")
+    c.simulate_batch_columns_device(poses, b, e, block.data_ptr(), st)
+    torch.cuda.synchronize()
+    for f, p in enumerate(poses):
+        one, _, _ = c.simulate(p, b, e)
+        assert np.array_equal(block[f].cpu().numpy().T, one[:, b:e]), f
+    with pytest.raises(native_lib.RRError, match="frame batch"):
+        c.simulate_batch_columns_device(np.tile(poses[0], (9, 1)), b, e, block.data_ptr(), st)
+    c.close()
