@@ -65,7 +65,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--ambient-noise", type=int, default=2)
     ap.add_argument("--strong", action="store_true", help="N>1: one frame per step + all-gather")
-    ap.add_argument("--force-slots", action="store_true", help="run the N>1 frame loop on one rank (debug)")
+    ap.add_argument("--force-slots", action="store_true", help="run the N>1 step loop (with its collective) on one rank (debug)")
+    ap.add_argument("--frames-per-step", type=int, default=1, help="N=1 only: whole frames per step (one set of launches)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +110,8 @@ def main():
     n_tris = len(scene["faces"])
 
     shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank),
-                         force_slots=args.force_slots, strong=args.strong)
+                         force_collective=args.force_slots, strong=args.strong,
+                         frames_per_step=args.frames_per_step)
     fps = shard.frames_per_step
     stream = torch.cuda.current_stream()
 

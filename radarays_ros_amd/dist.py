@@ -49,74 +49,79 @@ def gather_columns(cols_block, n_angles, world, group=None, out=None):
 
 
 class _Slot:
-    def __init__(self, n_frames, n_local, n_cells, n_angles, device):
+    def __init__(self, n_frames, n_images, n_local, n_cells, n_angles, device):
         self.stream = torch.cuda.Stream(device=device)
         self.block = torch.zeros((n_frames, n_local, n_cells), dtype=torch.uint8, device=device)
         self.cols = torch.zeros((n_angles, n_cells), dtype=torch.uint8, device=device)
-        self.image = torch.zeros((n_cells, n_angles), dtype=torch.uint8, device=device)
+        self.images = torch.zeros((n_images, n_cells, n_angles), dtype=torch.uint8, device=device)
         self.done = torch.cuda.Event()
 
 
 class AzimuthShard:
-    """Step loop of one rank (see module docstring)."""
+    """Step loop of one rank (see module docstring).
 
-    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3, force_slots=False, strong=False):
+    A step always runs on one of `n_slots` slot streams (own buffers) and NEVER waits on the
+    caller's stream -- that is what lets step k+1 overlap the tail (and, for world > 1, the
+    collective) of step k.  `wait(stream)` orders a consumer after the last step; an image
+    stays valid until `n_slots - 1` further steps have been enqueued.
+
+    world == 1: a step renders `frames_per_step` whole frames in one set of launches.
+    world  > 1: weak mode renders `world` frames per step (rank r ends up with frame r);
+                strong mode renders one frame per step (every rank ends up with it)."""
+
+    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3, strong=False,
+                 frames_per_step=1, force_collective=False):
         self.ctx, self.n_cells, self.n_angles = ctx, n_cells, n_angles
         self.rank, self.world, self.device = rank, world, device
         self.begin, self.end = partition(n_angles, world, rank)
         self.k = 0
-        self.sharded = world > 1 or force_slots      # force_slots: exercise the N>1 path on one rank
-        self.strong = strong or (n_angles % world != 0)
-        self.frames_per_step = 1 if (not self.sharded or self.strong) else world
-        if not self.sharded:
-            self.image = torch.zeros((n_cells, n_angles), dtype=torch.uint8, device=device)
+        self.collective = world > 1 or force_collective   # force_collective: run the N>1 code on one rank
+        self.strong = self.collective and (strong or n_angles % world != 0)
+        if not self.collective:
+            self.frames_per_step = int(frames_per_step)
         else:
-            self.slots = [_Slot(self.frames_per_step, self.end - self.begin, n_cells, n_angles, device)
-                          for _ in range(n_slots)]
+            self.frames_per_step = 1 if self.strong else world
+        n_images = self.frames_per_step if not self.collective else 1
+        self.slots = [_Slot(self.frames_per_step, n_images, self.end - self.begin, n_cells, n_angles, device)
+                      for _ in range(n_slots)]
+        self.last = None
 
     def frame(self, pose, stream=None):
-        """Single-frame entry (world == 1, or strong sharding): see step()."""
+        """Single-frame step (frames_per_step == 1)."""
         return self.step([pose], stream)
 
     def step(self, poses, stream=None):
-        """Enqueue one step = `frames_per_step` frames (poses: that many 7-float poses, the
-        same list on every rank) and return the HBM tensor that will hold THIS rank's mono8
-        image (weak mode: frame number `rank` of the step; otherwise the one frame).
-
-        world == 1: ordered on `stream` (default: current stream).
-        sharded  : asynchronous producer -- the step runs on one of `n_slots` slot streams and
-        NEVER waits on the caller's stream (that is what lets step k+1 overlap the collective
-        of step k).  Call `wait(stream)` before consuming; an image stays valid until
-        `n_slots - 1` further steps have been enqueued."""
+        """Enqueue one step (`frames_per_step` poses, the same list on every rank); returns the
+        HBM tensor [n_images][n_cells][n_angles] that will hold this rank's mono8 image(s)."""
         assert len(poses) == self.frames_per_step
-        stream = stream or torch.cuda.current_stream()
-        if not self.sharded:
-            # pipelining across frames happens inside the library (frame lanes)
-            self.ctx.simulate_device(poses[0], self.image.data_ptr(), stream.cuda_stream)
-            return self.image
         s = self.slots[self.k % len(self.slots)]
         self.k += 1
         with torch.cuda.stream(s.stream):
             sp = s.stream.cuda_stream
-            if self.strong:
-                self.ctx.simulate_columns_device(poses[0], self.begin, self.end, s.block.data_ptr(), None, sp)
-                cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.cols)
+            if not self.collective:
+                self.ctx.simulate_batch_columns_device(poses, 0, self.n_angles, s.block.data_ptr(), sp)
+                for f in range(self.frames_per_step):
+                    self.ctx.assemble_image_device(s.block[f].data_ptr(), s.images[f].data_ptr(), sp)
             else:
-                self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
-                # frame f's columns go to rank f; I receive every rank's block of frame `rank`,
-                # in rank order == azimuth order
-                dist.all_to_all_single(s.cols.view(-1), s.block.view(-1))
-                cols = s.cols
-            self.ctx.assemble_image_device(cols.data_ptr(), s.image.data_ptr(), sp)
+                if self.strong:
+                    self.ctx.simulate_columns_device(poses[0], self.begin, self.end, s.block.data_ptr(), None, sp)
+                    cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.cols)
+                else:
+                    self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
+                    # frame f's columns go to rank f; I receive every rank's block of frame `rank`,
+                    # in rank order == azimuth order
+                    dist.all_to_all_single(s.cols.view(-1), s.block.view(-1))
+                    cols = s.cols
+                self.ctx.assemble_image_device(cols.data_ptr(), s.images[0].data_ptr(), sp)
             s.done.record(s.stream)
         self.last = s
-        return s.image
+        return s.images
 
     def wait(self, stream=None):
-        """Make `stream` wait for the most recently enqueued step (sharded mode)."""
-        if self.sharded and getattr(self, "last", None) is not None:
+        """Make `stream` wait for the most recently enqueued step."""
+        if self.last is not None:
             (stream or torch.cuda.current_stream()).wait_event(self.last.done)
 
     def close(self):
-        self.image = None
         self.slots = None
+        self.last = None

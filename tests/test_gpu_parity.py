@@ -278,20 +278,29 @@ def test_sharded_slot_path_on_one_rank(native_lib):
                             device_id=torch.device("cuda", 0))
     try:
         dev = torch.device("cuda", 0)
-        sh = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, n_slots=3, force_slots=True)
+        sh = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, n_slots=3, force_collective=True)
         got = []
         assert sh.frames_per_step == 1
         for i, p in enumerate(poses):
             img = sh.frame(p)
             sh.wait()
-            got.append(img.clone())           # consume before the slot is reused
+            got.append(img[0].clone())        # consume before the slot is reused
         torch.cuda.synchronize()
         for g, w in zip(got, want):
             assert np.array_equal(g.cpu().numpy(), w)
-        # plain single-GPU path with frame lanes: back-to-back frames, last image wins
-        sh1 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev)
+        # strong mode (all-gather) on one rank
+        sh2 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, force_collective=True, strong=True)
+        img = sh2.frame(poses[2]); sh2.wait(); torch.cuda.synchronize()
+        assert np.array_equal(img[0].cpu().numpy(), want[2])
+        # single-GPU slots: 3 frames per step in one set of launches
+        sh1 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, frames_per_step=3)
+        imgs = sh1.step(poses[1:4]); sh1.wait(); torch.cuda.synchronize()
+        for f in range(3):
+            assert np.array_equal(imgs[f].cpu().numpy(), want[1 + f])
+        # stream-ordered library path with frame lanes: back-to-back frames, last image wins
+        img = torch.zeros((cfg.n_cells, 400), dtype=torch.uint8, device=dev)
         for p in poses:
-            img = sh1.frame(p)
+            c.simulate_device(p, img.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(img.cpu().numpy(), want[-1])
     finally:
@@ -319,3 +328,45 @@ def test_frame_batch_equals_single_frames(native_lib):
     with pytest.raises(native_lib.RRError, match="frame batch"):
         c.simulate_batch_columns_device(np.tile(poses[0], (9, 1)), b, e, block.data_ptr(), st)
     c.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_differential(native_lib, oracle, seed):
+    """Randomised scene / materials / config against the oracle (brute-force nearest hit)."""
+    rs = np.random.RandomState(1000 + seed)
+    room = scenes.box12()
+    verts, faces, obj = [room["verts"]], [room["faces"]], [room["face_object_id"]]
+    n_obj = 1 + rs.randint(1, 4)
+    vb = len(room["verts"])
+    for o in range(1, n_obj):                      # random boxes and free triangles inside the room
+        lo = rs.uniform([-8, -6, -0.9], [5, 4, 1.0])
+        hi = lo + rs.uniform(0.5, 3.0, 3)
+        v, f = scenes._box_tris(lo, hi, vbase=vb)
+        verts.append(v); faces.append(f); obj.append(np.full(12, o, np.uint32)); vb += 8
+        nt = rs.randint(0, 6)
+        if nt:
+            tv = (rs.uniform(-7, 7, (nt, 1, 3)) * [1, 0.8, 0.1] + rs.normal(0, 0.7, (nt, 3, 3))).astype(np.float32)
+            verts.append(tv.reshape(-1, 3)); faces.append((np.arange(3 * nt, dtype=np.uint32) + vb).reshape(nt, 3))
+            obj.append(np.full(nt, o, np.uint32)); vb += 3 * nt
+    s = {"verts": np.concatenate(verts), "faces": np.concatenate(faces), "face_object_id": np.concatenate(obj)}
+    mats = [params.RadarMaterial(0.3, 1.0, 0.0, 1.0)]
+    for _ in range(3):
+        mats.append(params.RadarMaterial(float(rs.choice([0.0, 0.05, 0.1, 0.2, 0.3, 0.45])), float(rs.uniform(0, 1)),
+                                         float(rs.uniform(0, 1)), float(rs.choice([1.0, 5.0, 30.0, 3000.0]))))
+    s["object_materials"] = [int(rs.randint(1, 4)) for _ in range(n_obj)]
+    cfg = params.kaist_preset(
+        n_reflections=int(rs.randint(1, 6)), ambient_noise=int(rs.choice([0, 0, 2, 1])),
+        signal_denoising=int(rs.choice([0, 1, 1, 2, 3])), record_multi_path=bool(rs.randint(0, 2)),
+        record_multi_reflection=bool(rs.randint(0, 2)), scroll_image=int(rs.randint(0, 400)),
+        signal_denoising_triangular_width=int(rs.randint(1, 120)), energy_max=float(rs.uniform(0.2, 1.0)),
+        signal_max=float(rs.uniform(50, 250)), resolution=float(rs.choice([0.0438, 0.0595238, 0.12])),
+        n_cells=int(rs.choice([3424, 777, 2048])), multipath_threshold=float(rs.uniform(0, 0.9)))
+    beams_ = golden_beams(int(rs.randint(1, 70)))
+    pose = scenes.yaw_pose(float(rs.uniform(-2, 2)), float(rs.uniform(-2, 2)), float(rs.uniform(-0.5, 2.0)),
+                           float(rs.uniform(-3.1, 3.1)))
+    q = rs.normal(0, 1, 4); q /= np.linalg.norm(q)
+    if seed % 3 == 0:
+        pose[:4] = q.astype(np.float32)            # arbitrary 3-D attitude, not only yaw
+    rnd = (rs.uniform(0, 1, 400) * 1000).astype(np.float32) if cfg.ambient_noise else None
+    a0 = int(rs.randint(0, 340))
+    _check(native_lib, oracle, s, cfg, mats, beams_, pose, (a0, a0 + 60), noise=rnd, use_bvh=0)
