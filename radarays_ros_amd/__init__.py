@@ -8,4 +8,4 @@ and the synthetic inputs of SURVEY.md §8d (scenes, beams).
 """
 from . import params, scenes, beams  # noqa: F401
 
-__all__ = ["params", "scenes", "beams", "native", "radar", "dist"]
+__all__ = ["params", "scenes", "beams", "meshio", "native", "radar", "dist"]
