@@ -370,3 +370,26 @@ def test_random_differential(native_lib, oracle, seed):
     rnd = (rs.uniform(0, 1, 400) * 1000).astype(np.float32) if cfg.ambient_noise else None
     a0 = int(rs.randint(0, 340))
     _check(native_lib, oracle, s, cfg, mats, beams_, pose, (a0, a0 + 60), noise=rnd, use_bvh=0)
+
+
+def test_degenerate_inputs(native_lib, oracle):
+    """n_reflections = 0 (Appendix A.1), an empty mesh (every wave misses), a single ray."""
+    s = gen.two_room_scene()
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    c = _ctx(native_lib, s, params.kaist_preset(n_reflections=0, ambient_noise=0), mats, golden_beams(8))
+    img, f32, st = c.simulate(scenes.default_pose("box12"), want_f32=True)
+    assert not img.any() and st["wave_passes"] == 0 and st["signals"] == 0
+    # empty mesh: hits = 0, columns 0 (x/0 -> NaN -> saturate_cast 0), f32 NaN like the CPU path
+    c.set_mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    c.set_config(params.kaist_preset(n_reflections=2, ambient_noise=0))
+    img, f32, st = c.simulate(scenes.default_pose("box12"), 0, 16, want_f32=True)
+    assert not img.any() and st["hits"] == 0 and st["wave_passes"] == 16 * 8 and np.isnan(f32[:, :16]).all()
+    # with noise on an empty column the reference also yields 0 (inf/NaN -> 0)
+    c.set_config(params.kaist_preset(n_reflections=1, ambient_noise=2))
+    c.set_noise_offsets(np.zeros(400, np.float32))
+    img, _, _ = c.simulate(scenes.default_pose("box12"), 0, 16)
+    assert not img.any()
+    c.close()
+    # one ray, one azimuth, one triangle pair
+    _check(native_lib, oracle, scenes.box12(), params.kaist_preset(n_reflections=3, ambient_noise=0),
+           params.kaist_materials(), np.float32([[1, 0, 0]]), scenes.yaw_pose(0, 0, 0, 0.0), (5, 6), use_bvh=0)
