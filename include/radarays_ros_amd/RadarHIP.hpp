@@ -1,0 +1,187 @@
+// RadarHIP.hpp -- C++ host side above the C ABI, mirroring the reference's backend interface.
+//
+// Reference (C++):  include/radarays_ros/Radar.hpp:34-105   abstract `Radar` (the seam:
+//                   `virtual sensor_msgs::ImagePtr simulate(ros::Time) = 0`, :64)
+//                   src/radarays_ros/Radar.cpp:10-41,188-226 ctor constants, updateDynCfg, loadParams
+//                   include/radarays_ros/RadarCPU.hpp:21-28  a concrete backend
+// This header keeps the same member names, argument meaning and error behaviour, minus the
+// ROS / OpenCV / rmagine types this image does not have: TF lookup becomes updateTsm(pose),
+// sensor_msgs::Image becomes the plain `Image` struct with the same fields, rm::Transform
+// becomes float[7] (quaternion xyzw + translation).  INTEGRATION.md shows the ROS-typed twin.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../radarays_mi355.h"
+
+namespace radarays_ros_amd {
+
+// msg/RadarMaterial.msg, msg/RadarModel.msg, msg/RadarParams.msg
+struct RadarMaterial { float velocity = 0.3f, ambient = 1.0f, diffuse = 0.0f, specular = 1.0f; };
+struct RadarModel { float beam_width = 8.0f * (float)M_PI / 180.0f; uint32_t n_samples = 200; uint32_t n_reflections = 2; };
+struct RadarParams { std::vector<RadarMaterial> materials; RadarModel model; };
+
+// cfg/RadarModel.cfg:11-85 (the fields the hot path reads; same names and defaults)
+struct RadarModelConfig {
+    double beam_width = 8.0, resolution = 0.0438;
+    int n_cells = 3424, n_samples = 10, beam_sample_dist = 2;
+    double beam_sample_dist_normal_p_in_cone = 0.8;
+    int n_reflections = 4;
+    double energy_max = 0.5, signal_max = 120.0;
+    int signal_denoising = 1;
+    int signal_denoising_triangular_width = 50; double signal_denoising_triangular_mode = 0.35;
+    int signal_denoising_gaussian_width = 50;   double signal_denoising_gaussian_mode = 0.5;
+    int signal_denoising_mb_width = 50;         double signal_denoising_mb_mode = 0.4;
+    int ambient_noise = 2;
+    double ambient_noise_at_signal_0 = 0.3, ambient_noise_at_signal_1 = 0.03;
+    double ambient_noise_energy_max = 0.5, ambient_noise_energy_min = 0.1, ambient_noise_energy_loss = 0.05;
+    int scroll_image = 0;
+    double multipath_threshold = 0.5;
+    bool record_multi_reflection = true, record_multi_path = false, include_motion = true;
+};
+
+// sensor_msgs/Image as RadarCPU.cpp:555-561 fills it
+struct Image {
+    double stamp = 0.0; std::string frame_id;
+    uint32_t height = 0, width = 0, step = 0; std::string encoding = "mono8";
+    std::vector<uint8_t> data;
+};
+using ImagePtr = std::shared_ptr<Image>;
+
+class Radar {   // Radar.hpp:34
+public:
+    Radar(std::string map_frame, std::string sensor_frame)
+    : m_map_frame(std::move(map_frame)), m_sensor_frame(std::move(sensor_frame)) {}   // Radar.cpp:10-41
+    virtual ~Radar() = default;
+
+    void loadParams(const std::vector<RadarMaterial>& materials, const std::vector<int>& object_materials,
+                    int material_id_air)   // Radar.cpp:220-226 (ROS parameter server -> arguments)
+    { m_params.materials = materials; m_object_materials = object_materials; m_material_id_air = material_id_air; m_dirty_mat = true; }
+    RadarParams getParams() const { return m_params; }
+    void setParams(const RadarParams& p) { m_params = p; m_dirty_mat = true; m_dirty_cfg = true; }
+
+    void updateDynCfg(const RadarModelConfig& config)   // Radar.cpp:188-218
+    {
+        if (config.beam_sample_dist != m_cfg.beam_sample_dist || std::abs(config.beam_width - m_cfg.beam_width) > 0.001 ||
+            config.n_samples != m_cfg.n_samples ||
+            std::abs(config.beam_sample_dist_normal_p_in_cone - m_cfg.beam_sample_dist_normal_p_in_cone) > 0.001)
+            m_resample = true;
+        m_params.model.beam_width = (float)(config.beam_width * M_PI / 180.0);
+        m_params.model.n_samples = (uint32_t)config.n_samples;
+        m_params.model.n_reflections = (uint32_t)config.n_reflections;
+        m_cfg = config; m_dirty_cfg = true;
+    }
+    bool updateTsm() const { return has_last; }                 // Radar.cpp:80-132: TF lookup, last pose as fallback
+    bool updateTsm(const float pose_qxyzw_t[7])
+    {
+        for (int k = 0; k < 7; k++) if (!std::isfinite(pose_qxyzw_t[k])) return has_last;
+        for (int k = 0; k < 7; k++) Tsm_last[k] = pose_qxyzw_t[k];
+        has_last = true; return true;
+    }
+    virtual ImagePtr simulate(double stamp) = 0;                 // Radar.hpp:64
+
+protected:
+    float Tsm_last[7] = { 0, 0, 0, 1, 0, 0, 0 }; bool has_last = false;
+    std::string m_map_frame, m_sensor_frame;
+    RadarParams m_params;
+    RadarModelConfig m_cfg;
+    int m_material_id_air = 0;                 // Radar.cpp:23
+    std::vector<int> m_object_materials;
+    float m_wave_energy_threshold = 0.001f;    // Radar.cpp:24
+    std::vector<float> m_waves_start;          // beam sample directions [n][3]
+    bool m_resample = true;                    // Radar.cpp:25
+    bool m_dirty_cfg = true, m_dirty_mat = true;
+};
+
+class RadarHIP : public Radar {   // sibling of RadarCPU (RadarCPU.hpp:16-37)
+public:
+    RadarHIP(std::string map_frame, std::string sensor_frame, const std::vector<float>& verts,
+             const std::vector<uint32_t>& faces, const std::vector<uint32_t>& face_object, int device = 0)
+    : Radar(std::move(map_frame), std::move(sensor_frame))
+    {
+        m_ctx = rr_create(device);
+        if (!m_ctx) throw std::runtime_error(rr_last_error(nullptr));
+        if (rr_set_mesh(m_ctx, verts.data(), verts.size() / 3, faces.data(), faces.size() / 3,
+                        face_object.empty() ? nullptr : face_object.data())) {
+            std::string e = rr_last_error(m_ctx); rr_destroy(m_ctx); throw std::runtime_error(e);
+        }
+    }
+    ~RadarHIP() override { rr_destroy(m_ctx); }
+    RadarHIP(const RadarHIP&) = delete;
+    RadarHIP& operator=(const RadarHIP&) = delete;
+
+    // m_waves_start: the reference draws them with sample_cone_local from std::random_device
+    // (RadarCPU.cpp:136-145); here they are supplied (any generator) -- [n][3], local frame
+    void setBeamSamples(const std::vector<float>& dirs) { m_waves_start = dirs; m_resample = false; m_push_beams = true; }
+    void setNoiseOffsets(const std::vector<float>& rnd) { rr_set_noise_offsets(m_ctx, rnd.data(), rnd.size()); }
+
+    ImagePtr simulate(double stamp) override   // RadarCPU.cpp:30-564
+    {
+        ImagePtr msg;
+        if (!updateTsm()) {
+            std::cout << "Couldn't get Transform between sensor and map. Skipping..." << std::endl;   // RadarCPU.cpp:131
+            return msg;
+        }
+        if (m_resample || m_waves_start.empty()) { m_err = "beam samples not set (setBeamSamples)"; return msg; }
+        if (m_dirty_cfg) {
+            rr_config c; rr_default_config(&c);
+            c.n_cells = m_cfg.n_cells; c.n_reflections = (int)m_params.model.n_reflections;
+            c.signal_denoising = m_cfg.signal_denoising;
+            c.signal_denoising_triangular_width = m_cfg.signal_denoising_triangular_width;
+            c.signal_denoising_triangular_mode = m_cfg.signal_denoising_triangular_mode;
+            c.signal_denoising_gaussian_width = m_cfg.signal_denoising_gaussian_width;
+            c.signal_denoising_gaussian_mode = m_cfg.signal_denoising_gaussian_mode;
+            c.signal_denoising_mb_width = m_cfg.signal_denoising_mb_width;
+            c.signal_denoising_mb_mode = m_cfg.signal_denoising_mb_mode;
+            c.ambient_noise = m_cfg.ambient_noise; c.scroll_image = m_cfg.scroll_image;
+            c.record_multi_reflection = m_cfg.record_multi_reflection; c.record_multi_path = m_cfg.record_multi_path;
+            c.multipath_threshold = m_cfg.multipath_threshold;
+            c.resolution = m_cfg.resolution; c.energy_max = m_cfg.energy_max; c.signal_max = m_cfg.signal_max;
+            c.ambient_noise_at_signal_0 = m_cfg.ambient_noise_at_signal_0;
+            c.ambient_noise_at_signal_1 = m_cfg.ambient_noise_at_signal_1;
+            c.ambient_noise_energy_max = m_cfg.ambient_noise_energy_max;
+            c.ambient_noise_energy_min = m_cfg.ambient_noise_energy_min;
+            c.ambient_noise_energy_loss = m_cfg.ambient_noise_energy_loss;
+            c.wave_energy_threshold = m_wave_energy_threshold;
+            if (rr_set_config(m_ctx, &c)) return fail();
+            m_n_angles = c.n_angles; m_dirty_cfg = false;
+        }
+        if (m_dirty_mat) {
+            std::vector<rr_material> mats(m_params.materials.size());
+            for (size_t i = 0; i < mats.size(); i++) {
+                const RadarMaterial& m = m_params.materials[i];
+                mats[i] = { m.velocity, m.ambient, m.diffuse, m.specular };
+            }
+            std::vector<int32_t> om(m_object_materials.begin(), m_object_materials.end());
+            if (rr_set_materials(m_ctx, mats.data(), mats.size(), om.data(), om.size(), m_material_id_air)) return fail();
+            m_dirty_mat = false;
+        }
+        if (m_push_beams) {
+            if (rr_set_beam_samples(m_ctx, m_waves_start.data(), m_waves_start.size() / 3)) return fail();
+            m_push_beams = false;
+        }
+        msg = std::make_shared<Image>();
+        msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;
+        msg->data.assign((size_t)msg->height * msg->width, 0);
+        if (rr_simulate(m_ctx, Tsm_last, 0, m_n_angles, msg->data.data(), nullptr, &m_stats)) { msg.reset(); return fail(); }
+        msg->stamp = stamp; msg->frame_id = m_sensor_frame;   // RadarCPU.cpp:560-561
+        return msg;
+    }
+    const std::string& lastError() const { return m_err; }
+    const rr_stats& lastStats() const { return m_stats; }
+
+private:
+    ImagePtr fail() { m_err = rr_last_error(m_ctx); std::cout << "[RadarHIP] " << m_err << std::endl; return {}; }
+    rr_ctx* m_ctx = nullptr;
+    int m_n_angles = 400;
+    bool m_push_beams = false;
+    rr_stats m_stats{};
+    std::string m_err;
+};
+
+}  // namespace radarays_ros_amd
