@@ -19,6 +19,7 @@ void launch_shade(const Params& P, int pass, hipStream_t s);
 void launch_scan(const Params& P, int pass, hipStream_t s);
 void launch_column(const Params& P, hipStream_t s);
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s);
+void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s);
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s);
 }  // namespace rr
@@ -61,6 +62,8 @@ struct Lane {
     DevBuf<SigRec> d_sigtmp, d_sig;
     DevBuf<float> d_hit_t, d_cols_f32;
     DevBuf<Counters> d_counters;
+    DevBuf<uint8_t> d_img_u8;     // host-buffer path: assembled image before the D2H copy
+    DevBuf<float> d_img_f32;
     DevBuf<SegStats> d_seg_stats;
     int last_n_seg = 0, last_n_passes = 0;
     int spill_stride = 0, stack_lds = 1;
@@ -473,7 +476,7 @@ void rr_destroy(rr_ctx* c)
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
         L.d_refpos.release();
         L.d_hit_tri.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
-        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_seg_stats.release();
+        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_seg_stats.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -699,23 +702,46 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
     if (out_f32) RR_HIP(c, L.d_cols_f32.ensure((size_t)L.buf_seg * g.n_cells));
     rc = run_frame(c, L, pose, az_begin, az_end, L.d_cols_u8.p, out_f32 ? L.d_cols_f32.p : nullptr, c->stream);
     if (rc) return rc;
-    std::vector<uint8_t> h8((size_t)n_seg * g.n_cells);
-    std::vector<float> hf(out_f32 ? (size_t)n_seg * g.n_cells : 0);
-    RR_HIP(c, hipMemcpyAsync(h8.data(), L.d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
-    if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), L.d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    RR_HIP(c, hipStreamSynchronize(c->stream));
-    for (int s = 0; s < n_seg; s++) {
-        const int col = (g.scroll_image + az_begin + s) % g.n_angles;   // RadarCPU.cpp:457
-        for (int i = 0; i < g.n_cells; i++) {
-            if (out_u8) out_u8[(size_t)i * g.n_angles + col] = h8[(size_t)s * g.n_cells + i];
-            if (out_f32) out_f32[(size_t)i * g.n_angles + col] = hf[(size_t)s * g.n_cells + i];
+    if (n_seg == g.n_angles) {
+        // whole frame: transpose on the GPU, one D2H copy straight into the caller's row-major buffer
+        const size_t npx = (size_t)g.n_cells * g.n_angles;
+        if (out_u8) {
+            RR_HIP(c, L.d_img_u8.ensure(npx));
+            launch_assemble_u8(L.d_cols_u8.p, L.d_img_u8.p, g.n_angles, g.n_cells, g.scroll_image, c->stream);
+            RR_HIP(c, hipMemcpyAsync(out_u8, L.d_img_u8.p, npx, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (out_f32) {
+            RR_HIP(c, L.d_img_f32.ensure(npx));
+            launch_assemble_f32(L.d_cols_f32.p, L.d_img_f32.p, g.n_angles, g.n_cells, g.scroll_image, c->stream);
+            RR_HIP(c, hipMemcpyAsync(out_f32, L.d_img_f32.p, npx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        }
+        RR_HIP(c, hipStreamSynchronize(c->stream));
+    } else {
+        std::vector<uint8_t> h8((size_t)n_seg * g.n_cells);
+        std::vector<float> hf(out_f32 ? (size_t)n_seg * g.n_cells : 0);
+        RR_HIP(c, hipMemcpyAsync(h8.data(), L.d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
+        if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), L.d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RR_HIP(c, hipStreamSynchronize(c->stream));
+        for (int s = 0; s < n_seg; s++) {
+            const int col = (g.scroll_image + az_begin + s) % g.n_angles;   // RadarCPU.cpp:457
+            for (int i = 0; i < g.n_cells; i++) {
+                if (out_u8) out_u8[(size_t)i * g.n_angles + col] = h8[(size_t)s * g.n_cells + i];
+                if (out_f32) out_f32[(size_t)i * g.n_angles + col] = hf[(size_t)s * g.n_cells + i];
+            }
         }
     }
-    rr_stats st;
-    rc = rr_get_stats(c, &st); if (rc) return rc;
-    if (stats) *stats = st;
-    if (st.overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
-    if (st.overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
+    uint32_t overflow = 0;
+    if (stats) {
+        rr_stats st;
+        rc = rr_get_stats(c, &st); if (rc) return rc;
+        *stats = st; overflow = st.overflow;
+    } else {
+        Counters h;
+        RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        overflow = h.overflow;
+    }
+    if (overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
+    if (overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
     return 0;
 }
 

@@ -833,6 +833,12 @@ void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_c
     hipLaunchKernelGGL((k_assemble<uint8_t>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll);
 }
 
+void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s)
+{
+    dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64), block(256);
+    hipLaunchKernelGGL((k_assemble<float>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll);
+}
+
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s)
 {
