@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--ambient-noise", type=int, default=2)
     ap.add_argument("--strong", action="store_true", help="N>1: one frame per step + all-gather")
     ap.add_argument("--force-slots", action="store_true", help="run the N>1 step loop (with its collective) on one rank (debug)")
-    ap.add_argument("--frames-per-step", type=int, default=1, help="N=1 only: whole frames per step (one set of launches)")
+    ap.add_argument("--frames-per-rank", type=int, default=4,
+                    help="frames each GPU finishes per step (one set of launches); a step = N x this many frames")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +112,7 @@ def main():
 
     shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank),
                          force_collective=args.force_slots, strong=args.strong,
-                         frames_per_step=args.frames_per_step)
+                         frames_per_rank=args.frames_per_rank)
     fps = shard.frames_per_step
     stream = torch.cuda.current_stream()
 

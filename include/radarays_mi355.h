@@ -144,7 +144,7 @@ int rr_simulate_columns_device(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_
                                uint8_t* d_cols_u8, float* d_cols_f32, void* stream);
 
 /* Frame batch (multi-GPU weak scaling, offline generation): the same azimuth block
- * [az_begin, az_end) of n_frames (1..8) different poses in ONE set of launches.
+ * [az_begin, az_end) of n_frames (1..32) different poses in ONE set of launches.
  * poses = [n_frames][7]; d_cols_u8 = [n_frames][az_end-az_begin][n_cells].  Kernels then see
  * n_frames x block segments, i.e. a rank that owns 1/N of the azimuths of N frames does the
  * same amount of work per launch as a single GPU does for one whole frame. */
@@ -156,6 +156,12 @@ int rr_simulate_batch_columns_device(rr_ctx* ctx, const float* poses, int n_fram
  * Device buffers, asynchronous on `stream`. */
 int rr_assemble_image_device(rr_ctx* ctx, const uint8_t* d_cols_u8 /*[n_angles][n_cells]*/,
                              uint8_t* d_img_u8 /*[n_cells][n_angles]*/, void* stream);
+
+/* Same for columns that arrive in blocks of n_loc azimuths `block_stride` BYTES apart (what a rank
+ * holds after the all_to_all of a multi-frame step: [source rank][frame][n_loc][n_cells]):
+ * azimuth a is read at d_cols + (a / n_loc) * block_stride + (a % n_loc) * n_cells. */
+int rr_assemble_blocks_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
+                              uint8_t* d_img_u8, void* stream);
 
 /* Convenience: rr_simulate_columns_device for all azimuths into the ctx's own
  * column buffer + rr_assemble_image_device into d_img_u8.  Asynchronous. */

@@ -18,7 +18,8 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s);
 void launch_shade(const Params& P, int pass, hipStream_t s);
 void launch_scan(const Params& P, int pass, hipStream_t s);
 void launch_column(const Params& P, hipStream_t s);
-void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s);
+void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
+                        int n_loc = 0, size_t block_stride = 0);
 void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s);
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s);
@@ -380,7 +381,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     const int n_loc = az_end - az_begin;
     const int n_seg = n_loc * n_frames;
     if (n_seg == 0) return 0;
-    if (n_frames < 1 || n_frames > 8) return fail(c, -3, "frame batch must be 1..8");
+    if (n_frames < 1 || n_frames > 32) return fail(c, -3, "frame batch must be 1..32");
     for (int k = 0; k < 7 * n_frames; k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
     int rc = upload_tables(c); if (rc) return rc;
     const int n_beam = (int)(c->beams.size() / 3);
@@ -617,6 +618,20 @@ int rr_assemble_image_device(rr_ctx* c, const uint8_t* d_cols_u8, uint8_t* d_img
     RR_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     { TimedScope t(c, s, "assemble"); launch_assemble_u8(d_cols_u8, d_img_u8, c->cfg.n_angles, c->cfg.n_cells, c->cfg.scroll_image, s); }
+    RR_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int rr_assemble_blocks_device(rr_ctx* c, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
+                              uint8_t* d_img_u8, void* stream)
+{
+    if (!c) return -1;
+    if (!c->have_cfg) return fail(c, -2, "rr_set_config has not been called");
+    if (!d_cols_u8 || !d_img_u8) return fail(c, -3, "rr_assemble_blocks_device: null buffer");
+    if (n_loc < 1 || c->cfg.n_angles % n_loc != 0) return fail(c, -3, "rr_assemble_blocks_device: n_loc must divide n_angles");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    { TimedScope t(c, s, "assemble"); launch_assemble_u8(d_cols_u8, d_img_u8, c->cfg.n_angles, c->cfg.n_cells, c->cfg.scroll_image, s, n_loc, block_stride); }
     RR_HIP(c, hipGetLastError());
     return 0;
 }

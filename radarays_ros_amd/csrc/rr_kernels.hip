@@ -767,14 +767,17 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_assemble(const T* __restrict__ cols, T* __restrict__ img,
-                                                  int n_angles, int n_cells, int scroll)
+                                                  int n_angles, int n_cells, int scroll,
+                                                  int n_loc, size_t block_stride)
 {
+    // azimuth a lives at cols + (a / n_loc) * block_stride + (a % n_loc) * n_cells
+    // (contiguous [n_angles][n_cells] when block_stride == n_loc * n_cells)
     __shared__ T tile[64][65];
     const int c0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) {
         const int a = a0 + r, c = c0 + tx;
-        if (a < n_angles && c < n_cells) tile[r][tx] = cols[(size_t)a * n_cells + c];
+        if (a < n_angles && c < n_cells) tile[r][tx] = cols[(size_t)(a / n_loc) * block_stride + (size_t)(a % n_loc) * n_cells + c];
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -827,16 +830,18 @@ void launch_column(const Params& P, hipStream_t s)
     hipLaunchKernelGGL(k_column, grid, block, (size_t)P.n_cells * sizeof(float), s, P);
 }
 
-void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s)
+void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
+                        int n_loc, size_t block_stride)
 {
     dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64), block(256);
-    hipLaunchKernelGGL((k_assemble<uint8_t>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll);
+    if (n_loc <= 0) { n_loc = n_angles; block_stride = (size_t)n_angles * n_cells; }
+    hipLaunchKernelGGL((k_assemble<uint8_t>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll, n_loc, block_stride);
 }
 
 void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s)
 {
     dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64), block(256);
-    hipLaunchKernelGGL((k_assemble<float>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll);
+    hipLaunchKernelGGL((k_assemble<float>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll, n_angles, (size_t)n_angles * n_cells);
 }
 
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,

@@ -52,7 +52,7 @@ class _Slot:
     def __init__(self, n_frames, n_images, n_local, n_cells, n_angles, device):
         self.stream = torch.cuda.Stream(device=device)
         self.block = torch.zeros((n_frames, n_local, n_cells), dtype=torch.uint8, device=device)
-        self.cols = torch.zeros((n_angles, n_cells), dtype=torch.uint8, device=device)
+        self.recv = torch.zeros((n_frames, n_local, n_cells), dtype=torch.uint8, device=device)
         self.images = torch.zeros((n_images, n_cells, n_angles), dtype=torch.uint8, device=device)
         self.done = torch.cuda.Event()
 
@@ -65,24 +65,25 @@ class AzimuthShard:
     collective) of step k.  `wait(stream)` orders a consumer after the last step; an image
     stays valid until `n_slots - 1` further steps have been enqueued.
 
-    world == 1: a step renders `frames_per_step` whole frames in one set of launches.
-    world  > 1: weak mode renders `world` frames per step (rank r ends up with frame r);
-                strong mode renders one frame per step (every rank ends up with it)."""
+    world == 1: a step renders `frames_per_rank` whole frames in one set of launches.
+    world  > 1: weak mode renders `world * frames_per_rank` frames per step (rank r ends up
+                with frames r*fpr .. r*fpr+fpr-1); strong mode renders one frame per step
+                (every rank ends up with it)."""
 
     def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3, strong=False,
-                 frames_per_step=1, force_collective=False):
+                 frames_per_rank=1, force_collective=False):
         self.ctx, self.n_cells, self.n_angles = ctx, n_cells, n_angles
         self.rank, self.world, self.device = rank, world, device
         self.begin, self.end = partition(n_angles, world, rank)
+        self.n_loc = self.end - self.begin
         self.k = 0
         self.collective = world > 1 or force_collective   # force_collective: run the N>1 code on one rank
         self.strong = self.collective and (strong or n_angles % world != 0)
-        if not self.collective:
-            self.frames_per_step = int(frames_per_step)
-        else:
-            self.frames_per_step = 1 if self.strong else world
-        n_images = self.frames_per_step if not self.collective else 1
-        self.slots = [_Slot(self.frames_per_step, n_images, self.end - self.begin, n_cells, n_angles, device)
+        self.fpr = 1 if self.strong else int(frames_per_rank)
+        self.frames_per_step = 1 if self.strong else self.fpr * world
+        if self.frames_per_step > 32:
+            raise ValueError("at most 32 frames per step")
+        self.slots = [_Slot(self.frames_per_step, self.fpr, self.n_loc, n_cells, n_angles, device)
                       for _ in range(n_slots)]
         self.last = None
 
@@ -92,27 +93,29 @@ class AzimuthShard:
 
     def step(self, poses, stream=None):
         """Enqueue one step (`frames_per_step` poses, the same list on every rank); returns the
-        HBM tensor [n_images][n_cells][n_angles] that will hold this rank's mono8 image(s)."""
+        HBM tensor [fpr][n_cells][n_angles] that will hold this rank's mono8 image(s)."""
         assert len(poses) == self.frames_per_step
         s = self.slots[self.k % len(self.slots)]
         self.k += 1
+        C, nl = self.n_cells, self.n_loc
         with torch.cuda.stream(s.stream):
             sp = s.stream.cuda_stream
-            if not self.collective:
-                self.ctx.simulate_batch_columns_device(poses, 0, self.n_angles, s.block.data_ptr(), sp)
-                for f in range(self.frames_per_step):
-                    self.ctx.assemble_image_device(s.block[f].data_ptr(), s.images[f].data_ptr(), sp)
-            else:
-                if self.strong:
-                    self.ctx.simulate_columns_device(poses[0], self.begin, self.end, s.block.data_ptr(), None, sp)
-                    cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.cols)
-                else:
-                    self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
-                    # frame f's columns go to rank f; I receive every rank's block of frame `rank`,
-                    # in rank order == azimuth order
-                    dist.all_to_all_single(s.cols.view(-1), s.block.view(-1))
-                    cols = s.cols
+            if self.strong:
+                self.ctx.simulate_columns_device(poses[0], self.begin, self.end, s.block.data_ptr(), None, sp)
+                cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.recv.view(-1)[:self.n_angles * C].view(self.n_angles, C))
                 self.ctx.assemble_image_device(cols.data_ptr(), s.images[0].data_ptr(), sp)
+            else:
+                self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
+                if self.collective:
+                    # frames d*fpr .. d*fpr+fpr-1 go to rank d; I receive [source rank][fpr][n_loc][C],
+                    # source-rank order == azimuth order
+                    dist.all_to_all_single(s.recv.view(-1), s.block.view(-1))
+                    src = s.recv
+                else:
+                    src = s.block
+                for j in range(self.fpr):
+                    self.ctx.assemble_blocks_device(src.data_ptr() + j * nl * C, nl, self.fpr * nl * C,
+                                                    s.images[j].data_ptr(), sp)
             s.done.record(s.stream)
         self.last = s
         return s.images

@@ -288,12 +288,17 @@ def test_sharded_slot_path_on_one_rank(native_lib):
         torch.cuda.synchronize()
         for g, w in zip(got, want):
             assert np.array_equal(g.cpu().numpy(), w)
+        # weak mode with 2 frames per rank and the all_to_all on one rank
+        sh3 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, force_collective=True, frames_per_rank=2)
+        imgs = sh3.step(poses[4:6]); sh3.wait(); torch.cuda.synchronize()
+        for f in range(2):
+            assert np.array_equal(imgs[f].cpu().numpy(), want[4 + f])
         # strong mode (all-gather) on one rank
         sh2 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, force_collective=True, strong=True)
         img = sh2.frame(poses[2]); sh2.wait(); torch.cuda.synchronize()
         assert np.array_equal(img[0].cpu().numpy(), want[2])
         # single-GPU slots: 3 frames per step in one set of launches
-        sh1 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, frames_per_step=3)
+        sh1 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, frames_per_rank=3)
         imgs = sh1.step(poses[1:4]); sh1.wait(); torch.cuda.synchronize()
         for f in range(3):
             assert np.array_equal(imgs[f].cpu().numpy(), want[1 + f])
@@ -326,7 +331,7 @@ def test_frame_batch_equals_single_frames(native_lib):
         one, _, _ = c.simulate(p, b, e)
         assert np.array_equal(block[f].cpu().numpy().T, one[:, b:e]), f
     with pytest.raises(native_lib.RRError, match="frame batch"):
-        c.simulate_batch_columns_device(np.tile(poses[0], (9, 1)), b, e, block.data_ptr(), st)
+        c.simulate_batch_columns_device(np.tile(poses[0], (33, 1)), b, e, block.data_ptr(), st)
     c.close()
 
 

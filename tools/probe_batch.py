@@ -25,5 +25,10 @@ torch.cuda.synchronize(); t0 = time.time()
 for k in range(K): step(k)
 te = time.time() - t0
 torch.cuda.synchronize(); dt = time.time() - t0
+c.set_timing_mode(2)
+for k in range(200): step(k)
+torch.cuda.synchronize()
+ms, n = c.kernel_time("trace", True)
+print("  k_trace avg %.1f us over %d launches (%.0f rays/launch)" % (1e3 * ms / n, n, F * 80000))
 print("F=%d frames/s %.1f  us/frame %.1f (host %.1f us/frame)" % (F, K * F / dt, 1e6 * dt / (K * F), 1e6 * te / (K * F)))
 c.close()
