@@ -4,18 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-A step = one polar image (400 azimuths x 3424 range bins, mono8) of the workload
-BASELINE.json's metric is quoted on (configs[1]): 400 azimuths x 200 rays, 1 ray-cast
-pass, 100k-triangle synthetic mesh, KAIST parameter preset (cfg/mulran_kaist_dyncfg.yaml)
+A step = one batch of `--frames-per-rank` (default 4) poses per GPU, each rendered to one polar
+image (400 azimuths x 3424 range bins, mono8) of the workload BASELINE.json's metric is
+quoted on (configs[1]): 400 azimuths x 200 rays, 1 ray-cast pass, 100k-triangle synthetic mesh, KAIST parameter preset (cfg/mulran_kaist_dyncfg.yaml)
 including the Perlin ambient-noise stage with injected per-column offsets.  Mesh, BVH,
 parameters and beam samples are resident in HBM before the timed region; poses are 7
 floats passed as kernel arguments; the image stays in HBM.
 
 N > 1 (north_star): the 400 azimuth columns of EVERY frame are sharded over the ranks
 (400/N columns each) and assembled by ONE RCCL collective over xGMI per step
-(default, "scaling": "weak"): a step renders N frames; rank r simulates its 400/N-column
-block of all N frames in one set of launches and ONE all_to_all_single (the N per-frame
-gathers fused) hands frame f to rank f -- per-GPU work per step is constant, value = N*K/t.
+(default, "scaling": "weak"): a step renders N*F frames; rank r simulates its 400/N-column
+block of all of them in one set of launches and ONE all_to_all_single (the per-frame
+gathers fused) hands frames d*F.. to rank d -- per-GPU work per step is constant,
+value = N*F*K/t.
 `--strong`: one frame per step + one all-gather (latency mode).
 
 Extra objects on the JSON line: "roofline" (dominant kernel = k_trace, hipEvent-timed on
