@@ -214,10 +214,10 @@ int upload_tables(rr_ctx* c)
     if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
     {
         // trace order of pass 0: Morton order of the direction's (y, z) so that a quad /
-        // wave holds neighbouring rays of the cone (RR_DEBUG bit 8 disables it)
+        // wave holds neighbouring rays of the cone (RR_NO_BEAM_SORT=1 disables it: A/B experiments)
         std::vector<uint32_t> order(nb);
         for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
-        const bool no_sort = getenv("RR_DEBUG") && (atoi(getenv("RR_DEBUG")) & 8);
+        const bool no_sort = getenv("RR_NO_BEAM_SORT") && atoi(getenv("RR_NO_BEAM_SORT")) != 0;
         if (nb > 1 && !no_sort) {
             float lo[2] = { 1e30f, 1e30f }, hi[2] = { -1e30f, -1e30f };
             for (size_t i = 0; i < nb; i++) for (int k = 0; k < 2; k++) {
@@ -347,8 +347,6 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.noise_e_loss = g.ambient_noise_energy_loss;
     P.spill_stride = L.spill_stride; P.stack_lds = L.stack_lds;
     P.spill_depth = std::max(0, (int)c->stack_need - L.stack_lds);
-    static const int dbg = getenv("RR_DEBUG") ? atoi(getenv("RR_DEBUG")) : 0;
-    P.debug = dbg;
 }
 
 struct TimedScope {
@@ -689,7 +687,7 @@ int rr_get_stats(rr_ctx* c, rr_stats* st)
     Counters h;
     RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
     st->nodes_visited = h.nodes; st->tris_tested = h.tris; st->overflow = h.overflow;
-    if (getenv("RR_DEBUG")) fprintf(stderr, "[rr stats] waves %u wave_iters %llu (avg %.1f) max_iters %u\n", h.n_waves, h.wave_iters, h.n_waves ? (double)h.wave_iters / h.n_waves : 0.0, h.max_iters);
+    if (getenv("RR_TRACE_STATS")) fprintf(stderr, "[rr stats] waves %u wave_iters %llu (avg %.1f) max_iters %u\n", h.n_waves, h.wave_iters, h.n_waves ? (double)h.wave_iters / h.n_waves : 0.0, h.max_iters);
     const size_t n = (size_t)L.last_n_seg * (size_t)L.last_n_passes;
     if (n && L.d_seg_stats.p) {
         std::vector<SegStats> ss(n);

@@ -122,7 +122,6 @@ struct Params {
     double signal_max;
     double noise_at_0, noise_at_1, noise_e_max, noise_e_min, noise_e_loss;
     int spill_stride, stack_lds, spill_depth;
-    int debug;                   // RR_DEBUG env bits (perf experiments only)
 };
 
 }  // namespace rr

@@ -212,9 +212,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     unsigned nn = 0, nt = 0;
     if (active) {
         const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
-        Hit h; h.t = 1.0f; h.tri = 0; h.face = 0;
-        if (!(P.debug & 32))
-            h = traverse<STATS, SPILL>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
+        const Hit h = traverse<STATS, SPILL>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
@@ -642,7 +640,6 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         if (tid < 2) s_tiles[tid] = 0ull;
         __syncthreads();
         for (int i = tid; i < n; i += kColThreads) {
-            if (P.debug & 4) break;
             const int v = c0 + i;
             SigRec r;
             if (v < n_list) r = P.sig[(size_t)seg * P.sigcap + v];
@@ -661,7 +658,6 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         }
         __syncthreads();
         for (int t = wid; t < n_tiles; t += kColWaves) {
-            if (P.debug & 1) break;
             if (!((s_tiles[t >> 6] >> (t & 63)) & 1ull)) continue;
             const int g = t * 64 + lane;
             const int tlo = t * 64, thi = tlo + 63;
@@ -723,7 +719,6 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[angle_id] : 0.0f;
 
     for (int i = tid; i < n_cells; i += kColThreads) {
-        if (P.debug & 2) break;
         float v = lds_col[i] * P.energy_max_f;   // :453
         if (P.ambient_noise) {   // :459-528
             const float signal = v;
