@@ -21,6 +21,10 @@ void launch_column(const Params& P, hipStream_t s);
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
                         int n_loc = 0, size_t block_stride = 0);
 void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s);
+bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object,
+                    Node4** d_nodes_out, size_t* n_nodes_out, TriRec** d_tris_out,
+                    uint32_t* depth_out, uint32_t* stack_need_out, float* inflate_out,
+                    std::string& err, hipStream_t stream);
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s);
 }  // namespace rr
@@ -503,6 +507,27 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     c->depth = bvh.depth; c->stack_need = bvh.stack_need;
     c->have_mesh = true;
     for (Lane& L : c->lanes) { if (L.stream) RR_HIP(c, hipStreamSynchronize(L.stream)); L.buf_seg = 0; }   // stack geometry may have changed
+    return 0;
+}
+
+int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces, size_t nf,
+                    const uint32_t* face_object_id)
+{
+    if (!c) return -1;
+    if (nf == 0) return rr_set_mesh(c, verts, nv, faces, nf, face_object_id);
+    if (!verts || !faces) return fail(c, -4, "rr_set_mesh_gpu: null vertex/face pointer");
+    RR_HIP(c, hipSetDevice(c->device));
+    RR_HIP(c, hipDeviceSynchronize());
+    Node4* dn = nullptr; TriRec* dt = nullptr; size_t nn = 0; uint32_t depth = 0, need = 0; float inflate = 0.f;
+    std::string err;
+    if (!build_bvh4_gpu(verts, nv, faces, nf, face_object_id, &dn, &nn, &dt, &depth, &need, &inflate, err, c->stream))
+        return fail(c, -4, err);
+    c->d_nodes.release(); c->d_tris.release();
+    c->d_nodes.p = dn; c->d_nodes.n = nf + 1;
+    c->d_tris.p = dt; c->d_tris.n = nf + 4;
+    c->n_nodes = nn; c->n_tris = nf; c->depth = depth; c->stack_need = need;
+    c->have_mesh = true;
+    for (Lane& L : c->lanes) L.buf_seg = 0;
     return 0;
 }
 

@@ -15,7 +15,7 @@ _LIB = None
 
 SYMBOLS = [
     "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
-    "rr_set_mesh", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
+    "rr_set_mesh", "rr_set_mesh_gpu", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
     "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device", "rr_simulate_batch_columns_device",
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_simulate_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
@@ -93,6 +93,7 @@ def lib():
     L.rr_last_error.restype = C.c_char_p
     L.rr_last_error.argtypes = [vp]
     L.rr_set_mesh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.rr_set_mesh_gpu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
     L.rr_set_materials.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int32]
     L.rr_set_config.argtypes = [vp, C.POINTER(RRConfig)]
     L.rr_set_beam_samples.argtypes = [vp, vp, C.c_size_t]
@@ -181,14 +182,14 @@ class Context:
         if rc != 0:
             raise RRError("%s (rc=%d)" % (self._L.rr_last_error(self._h).decode(), rc))
 
-    def set_mesh(self, verts, faces, face_object_id=None):
+    def set_mesh(self, verts, faces, face_object_id=None, builder="host"):
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
         o = None if face_object_id is None else np.ascontiguousarray(face_object_id, np.uint32)
         if o is not None and len(o) != len(f):
             raise ValueError("face_object_id must have one entry per face")
-        self._ck(self._L.rr_set_mesh(self._h, v.ctypes.data, len(v), f.ctypes.data, len(f),
-                                     None if o is None else o.ctypes.data))
+        fn = {"host": self._L.rr_set_mesh, "gpu": self._L.rr_set_mesh_gpu}[builder]
+        self._ck(fn(self._h, v.ctypes.data, len(v), f.ctypes.data, len(f), None if o is None else o.ctypes.data))
 
     def set_materials(self, materials, object_materials, material_id_air=0):
         m = (RRMaterial * len(materials))(*[RRMaterial(*[float(x) for x in (t.astuple() if hasattr(t, "astuple") else t)])

@@ -398,3 +398,38 @@ def test_degenerate_inputs(native_lib, oracle):
     # one ray, one azimuth, one triangle pair
     _check(native_lib, oracle, scenes.box12(), params.kaist_preset(n_reflections=3, ambient_noise=0),
            params.kaist_materials(), np.float32([[1, 0, 0]]), scenes.yaw_pose(0, 0, 0, 0.0), (5, 6), use_bvh=0)
+
+
+def test_gpu_bvh_builder_gives_identical_images(native_lib):
+    """rr_set_mesh_gpu (Morton + radix sort + Karras + collapse on the GPU): the nearest hit is
+    defined independently of traversal order, so frames are bit-identical to the host-SAH tree."""
+    rs = np.random.RandomState(11)
+    for s, nb, npass in ((gen.two_room_scene(), 48, 4), (scenes.heightfield_room(96, n_buildings=40), 64, 3),
+                         (scenes.box12(), 16, 2)):
+        mats = materials_for(s) if max(s["object_materials"]) < 2 else params.kaist_materials() + [params.PENETRABLE]
+        cfg = params.kaist_preset(n_reflections=npass, ambient_noise=0)
+        pose = scenes.default_pose(s["name"])
+        c = _ctx(native_lib, s, cfg, mats, golden_beams(nb))
+        a8, af, ast = c.simulate(pose, want_f32=True)
+        o = rs.uniform(-5, 5, (4000, 3)).astype(np.float32) + pose[4:7]
+        d = rs.normal(0, 1, (4000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        t0, f0 = c.debug_trace(o, d)
+        c.set_mesh(s["verts"], s["faces"], s["face_object_id"], builder="gpu")
+        info = c.bvh_info()
+        assert info["n_tris"] == len(s["faces"]) and info["depth"] >= 1
+        b8, bf, bst = c.simulate(pose, want_f32=True)
+        t1, f1 = c.debug_trace(o, d)
+        assert np.array_equal(t0, t1) and np.array_equal(f0, f1)
+        assert np.array_equal(a8, b8) and np.array_equal(af, bf, equal_nan=True)
+        assert {k: ast[k] for k in ("wave_passes", "hits", "signals")} == {k: bst[k] for k in ("wave_passes", "hits", "signals")}
+        c.close()
+    # a single triangle and duplicate centroids
+    c = native_lib.Context(0)
+    c.set_mesh(np.float32([[0, 0, 5], [1, 0, 5], [0, 1, 5]]), np.uint32([[0, 1, 2]]), builder="gpu")
+    t, f = c.debug_trace(np.float32([[0.2, 0.2, 0]]), np.float32([[0, 0, 1]]))
+    assert t[0] == 5.0 and f[0] == 0
+    v = np.float32([[0, 0, 5], [1, 0, 5], [0, 1, 5]]); vv = np.concatenate([v + [0, 0, k * 0.0] for k in range(9)])
+    c.set_mesh(vv, np.arange(27, dtype=np.uint32).reshape(9, 3), builder="gpu")      # 9 coincident triangles
+    t, f = c.debug_trace(np.float32([[0.2, 0.2, 0]]), np.float32([[0, 0, 1]]))
+    assert t[0] == 5.0 and f[0] == 0                                                # lowest face id wins the tie
+    c.close()

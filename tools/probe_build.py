@@ -1,0 +1,23 @@
+import sys, time, os, numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+from radarays_ros_amd import native, params, scenes
+from common import golden_beams, materials_for
+import torch
+cid = int(sys.argv[1]); npass = int(sys.argv[2])
+s = scenes.config_scene(cid)
+cfg = params.kaist_preset(n_reflections=npass, ambient_noise=0)
+c = native.Context(0)
+c.set_materials(materials_for(s), s["object_materials"], 0); c.set_config(cfg); c.set_beam_samples(golden_beams(200))
+poses = scenes.trajectory(16, s["name"])
+img = torch.zeros((cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+out = {}
+for b in ("host", "gpu", "gpu"):
+    t0 = time.time(); c.set_mesh(s["verts"], s["faces"], s["face_object_id"], builder=b); tb = time.time() - t0
+    for p in poses[:3]: c.simulate_device(p, img.data_ptr(), None)
+    c.synchronize(); t0 = time.time()
+    for k in range(40): c.simulate_device(poses[k % 16], img.data_ptr(), None)
+    c.synchronize(); dt = (time.time() - t0) / 40
+    out[b] = img.cpu().numpy().copy()
+    print("%s: build %.3f s  %s  frame %.3f ms" % (b, tb, c.bvh_info(), 1e3 * dt))
+print("identical images:", np.array_equal(out["host"], out["gpu"]))
+c.close()
