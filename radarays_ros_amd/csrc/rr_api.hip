@@ -14,7 +14,7 @@
 #include <vector>
 
 namespace rr {
-void launch_trace(const Params& P, int pass, bool stats, hipStream_t s);
+void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_shade(const Params& P, int pass, hipStream_t s);
 void launch_scan(const Params& P, int pass, hipStream_t s);
 void launch_column(const Params& P, hipStream_t s);
@@ -357,7 +357,7 @@ struct TimedScope {
     rr_ctx* c; hipStream_t s; const char* name; hipEvent_t a = nullptr, b = nullptr;
     bool on;
     TimedScope(rr_ctx* c_, hipStream_t s_, const char* n_) : c(c_), s(s_), name(n_) {
-        on = c->timing == 1 || (c->timing == 2 && std::strcmp(name, "trace") == 0);
+        on = c->timing == 1;
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~TimedScope() {
@@ -399,7 +399,15 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
     L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
     for (int pass = 0; pass < g.n_reflections; pass++) {
-        { TimedScope t(c, s, "trace"); launch_trace(P, pass, c->stats_mode, s); }
+        if (c->timing) {
+            // the kernel's own begin/end timestamps (hipExtLaunchKernel events), on its launch stream
+            hipEvent_t a = nullptr, b = nullptr;
+            RR_HIP(c, hipEventCreate(&a)); RR_HIP(c, hipEventCreate(&b));
+            launch_trace(P, pass, c->stats_mode, s, a, b);
+            c->timers["trace"].pending.emplace_back(a, b);
+        } else {
+            launch_trace(P, pass, c->stats_mode, s);
+        }
         { TimedScope t(c, s, "shade"); launch_shade(P, pass, s); }
         if (pass < g.n_reflections - 1) { TimedScope t(c, s, "scan"); launch_scan(P, pass, s); }
     }

@@ -13,6 +13,7 @@
 // prefix-sum based (no atomics), so the signal list of an azimuth is in exactly
 // the reference's order and the image does not depend on scheduling.
 #include "rr_device.h"
+#include <hip/hip_ext.h>
 
 namespace rr {
 
@@ -787,13 +788,15 @@ __global__ __launch_bounds__(256) void k_assemble(const T* __restrict__ cols, T*
 // ---------------------------------------------------------------------------
 // launchers (called from rr_api.cpp through plain C++ prototypes)
 // ---------------------------------------------------------------------------
-void launch_trace(const Params& P, int pass, bool stats, hipStream_t s)
+void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int cap_p = pass == 0 ? P.n_beam : P.cap;
     dim3 grid((cap_p + kRaysPerBlock - 1) / kRaysPerBlock, P.n_seg), block(kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
     const bool spill = P.spill_depth > 0;
-#define RR_LAUNCH_TRACE(F, S, X) hipLaunchKernelGGL((k_trace<F, S, X>), grid, block, lds, s, P, pass)
+// hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
+    // rocprofv3 reports), not the time the launch spent waiting for CUs held by other streams
+#define RR_LAUNCH_TRACE(F, S, X) hipExtLaunchKernelGGL((k_trace<F, S, X>), grid, block, lds, s, ev_start, ev_stop, 0, P, pass)
     if (pass == 0) {
         if (stats) { if (spill) RR_LAUNCH_TRACE(true, true, true); else RR_LAUNCH_TRACE(true, true, false); }
         else       { if (spill) RR_LAUNCH_TRACE(true, false, true); else RR_LAUNCH_TRACE(true, false, false); }
