@@ -19,6 +19,8 @@ plumbing here: device buffers, streams, the collective.  Steps are pipelined ove
 few slots (own HIP stream + buffers) so the collective of step k overlaps the
 kernels of step k+1.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -50,11 +52,14 @@ def gather_columns(cols_block, n_angles, world, group=None, out=None):
 
 class _Slot:
     def __init__(self, n_frames, n_images, n_local, n_cells, n_angles, device):
-        self.stream = torch.cuda.Stream(device=device)
+        # (a CPU device is accepted only so that the step logic can be driven by a mock context in the
+        # world-size-2 gloo tests; the product always runs on cuda devices)
+        self.stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
         self.block = torch.zeros((n_frames, n_local, n_cells), dtype=torch.uint8, device=device)
-        self.recv = torch.zeros((n_frames, n_local, n_cells), dtype=torch.uint8, device=device)
+        # weak: [source rank][fpr][n_local][cells] (same size as block); strong: the gathered [n_angles][cells]
+        self.recv = torch.zeros((max(n_frames * n_local, n_angles), n_cells), dtype=torch.uint8, device=device)
         self.images = torch.zeros((n_images, n_cells, n_angles), dtype=torch.uint8, device=device)
-        self.done = torch.cuda.Event()
+        self.done = torch.cuda.Event() if device.type == "cuda" else None
 
 
 class AzimuthShard:
@@ -98,31 +103,32 @@ class AzimuthShard:
         s = self.slots[self.k % len(self.slots)]
         self.k += 1
         C, nl = self.n_cells, self.n_loc
-        with torch.cuda.stream(s.stream):
-            sp = s.stream.cuda_stream
+        with (torch.cuda.stream(s.stream) if s.stream is not None else contextlib.nullcontext()):
+            sp = s.stream.cuda_stream if s.stream is not None else None
             if self.strong:
                 self.ctx.simulate_columns_device(poses[0], self.begin, self.end, s.block.data_ptr(), None, sp)
-                cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.recv.view(-1)[:self.n_angles * C].view(self.n_angles, C))
+                cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.recv[:self.n_angles])
                 self.ctx.assemble_image_device(cols.data_ptr(), s.images[0].data_ptr(), sp)
             else:
                 self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
                 if self.collective:
                     # frames d*fpr .. d*fpr+fpr-1 go to rank d; I receive [source rank][fpr][n_loc][C],
                     # source-rank order == azimuth order
-                    dist.all_to_all_single(s.recv.view(-1), s.block.view(-1))
+                    dist.all_to_all_single(s.recv[:self.frames_per_step * nl].view(-1), s.block.view(-1))
                     src = s.recv
                 else:
                     src = s.block
                 for j in range(self.fpr):
                     self.ctx.assemble_blocks_device(src.data_ptr() + j * nl * C, nl, self.fpr * nl * C,
                                                     s.images[j].data_ptr(), sp)
-            s.done.record(s.stream)
+            if s.done is not None:
+                s.done.record(s.stream)
         self.last = s
         return s.images
 
     def wait(self, stream=None):
         """Make `stream` wait for the most recently enqueued step."""
-        if self.last is not None:
+        if self.last is not None and self.last.done is not None:
             (stream or torch.cuda.current_stream()).wait_event(self.last.done)
 
     def close(self):

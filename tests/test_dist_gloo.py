@@ -118,3 +118,92 @@ def test_two_rank_weak_step_all_to_all(tmp_path, oracle):
     mp.spawn(_worker_weak, args=(2, port, 40, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))[0] == 1
+
+
+class _MockCtx:
+    """Stands in for native.Context in the CPU run of AzimuthShard: same entry points, same
+    pointer/stride contracts, columns computed by the oracle (test infrastructure)."""
+
+    def __init__(self, O, sc, mats, objm, cfg, beams, n_angles):
+        self.O, self.sc, self.mats, self.objm, self.cfg, self.beams, self.A = O, sc, mats, objm, cfg, beams, n_angles
+        self.C = cfg.n_cells
+
+    def _view(self, ptr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr))
+
+    def _cols(self, pose, b, e):
+        u8, _, _ = self.O.simulate(self.sc, self.mats, self.objm, self.cfg.copy(scroll_image=0), self.beams, pose,
+                                   az_begin=b, az_end=e, n_angles=self.A, n_threads=1)
+        return np.ascontiguousarray(u8[:, b:e].T)
+
+    def simulate_columns_device(self, pose, b, e, ptr, f32, sp):
+        self._view(ptr, (e - b) * self.C)[:] = self._cols(pose, b, e).ravel()
+
+    def simulate_batch_columns_device(self, poses, b, e, ptr, sp):
+        n = (e - b) * self.C
+        v = self._view(ptr, len(poses) * n)
+        for f, p in enumerate(poses):
+            v[f * n:(f + 1) * n] = self._cols(p, b, e).ravel()
+
+    def assemble_blocks_device(self, ptr, n_loc, stride, img_ptr, sp):
+        img = self._view(img_ptr, self.C * self.A).reshape(self.C, self.A)
+        for a in range(self.A):
+            col = self._view(ptr + (a // n_loc) * stride + (a % n_loc) * self.C, self.C)
+            img[:, (self.cfg.scroll_image + a) % self.A] = col
+
+    def assemble_image_device(self, ptr, img_ptr, sp):
+        self.assemble_blocks_device(ptr, self.A, self.A * self.C, img_ptr, sp)
+
+
+def _worker_shard(rank, world, port, out_dir):
+    """The REAL AzimuthShard step loop (weak fpr=2 and strong) on 2 gloo ranks with a mock context."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from radarays_ros_amd import params, scenes
+    from radarays_ros_amd.dist import AzimuthShard
+    from common import golden_beams, mats_tuple
+    import gen_oracle_images as gen
+    A = 40
+    s = gen.two_room_scene()
+    cfg = params.kaist_preset(n_reflections=2, ambient_noise=0, n_cells=256, resolution=0.2, scroll_image=3)
+    sc = O.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
+    mats = mats_tuple(params.kaist_materials() + [params.PENETRABLE])
+    ctx = _MockCtx(O, sc, mats, s["object_materials"], cfg, golden_beams(6), A)
+    poses = scenes.trajectory(8, "box12")
+    full = lambda p: O.simulate(sc, mats, s["object_materials"], cfg, golden_beams(6), p, n_angles=A, n_threads=1)[0]
+    ok = 1
+    dev = torch.device("cpu")
+    weak = AzimuthShard(ctx, cfg.n_cells, A, rank, world, dev, n_slots=2, frames_per_rank=2)
+    assert weak.frames_per_step == 4
+    for k in range(3):                                   # 3 steps over 2 slots: slot reuse included
+        step_poses = [poses[(k * 4 + f) % 8] for f in range(4)]
+        imgs = weak.step(step_poses)
+        for j in range(2):                               # I own frames rank*2 + j of the step
+            ok &= int(np.array_equal(imgs[j].numpy(), full(step_poses[rank * 2 + j])))
+    strong = AzimuthShard(ctx, cfg.n_cells, A, rank, world, dev, n_slots=2, strong=True)
+    assert strong.frames_per_step == 1
+    for k in range(2):
+        img = strong.step([poses[k]])
+        ok &= int(np.array_equal(img[0].numpy(), full(poses[k])))
+    ragged = AzimuthShard(ctx.__class__(O, sc, mats, s["object_materials"], cfg, golden_beams(6), 41), cfg.n_cells, 41,
+                          rank, world, dev)            # 41 % 2 != 0 -> falls back to the gather mode
+    assert ragged.strong and ragged.frames_per_step == 1
+    img = ragged.step([poses[5]])
+    want = O.simulate(sc, mats, s["object_materials"], cfg, golden_beams(6), poses[5], n_angles=41, n_threads=1)[0]
+    ok &= int(np.array_equal(img[0].numpy(), want))
+    np.save(os.path.join(out_dir, "shard%d.npy" % rank), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_azimuth_shard_step_loop(tmp_path, oracle):
+    port = _free_port()
+    mp.spawn(_worker_shard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(os.path.join(str(tmp_path), "shard%d.npy" % r))[0] == 1
