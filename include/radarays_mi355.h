@@ -171,6 +171,11 @@ int rr_assemble_image_device(rr_ctx* ctx, const uint8_t* d_cols_u8 /*[n_angles][
 int rr_assemble_blocks_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
                               uint8_t* d_img_u8, void* stream);
 
+/* All frames of a multi-frame step in ONE launch: frame j reads its columns frame_stride bytes after
+ * frame j-1 (block addressing as above) and writes image j of d_imgs_u8 [n_frames][n_cells][n_angles]. */
+int rr_assemble_frames_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
+                              int n_frames, size_t frame_stride, uint8_t* d_imgs_u8, void* stream);
+
 /* Convenience: rr_simulate_columns_device for all azimuths into the ctx's own
  * column buffer + rr_assemble_image_device into d_img_u8.  Asynchronous. */
 int rr_simulate_device(rr_ctx* ctx, const float pose_qxyzw_t[7], uint8_t* d_img_u8, void* stream);

@@ -19,7 +19,7 @@ void launch_shade(const Params& P, int pass, hipStream_t s);
 void launch_scan(const Params& P, int pass, hipStream_t s);
 void launch_column(const Params& P, hipStream_t s);
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
-                        int n_loc = 0, size_t block_stride = 0);
+                        int n_loc = 0, size_t block_stride = 0, int n_frames = 1, size_t frame_stride = 0);
 void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s);
 bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object,
                     Node4** d_nodes_out, size_t* n_nodes_out, TriRec** d_tris_out,
@@ -649,6 +649,21 @@ int rr_assemble_image_device(rr_ctx* c, const uint8_t* d_cols_u8, uint8_t* d_img
     RR_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     { TimedScope t(c, s, "assemble"); launch_assemble_u8(d_cols_u8, d_img_u8, c->cfg.n_angles, c->cfg.n_cells, c->cfg.scroll_image, s); }
+    RR_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int rr_assemble_frames_device(rr_ctx* c, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
+                              int n_frames, size_t frame_stride, uint8_t* d_imgs_u8, void* stream)
+{
+    if (!c) return -1;
+    if (!c->have_cfg) return fail(c, -2, "rr_set_config has not been called");
+    if (!d_cols_u8 || !d_imgs_u8) return fail(c, -3, "rr_assemble_frames_device: null buffer");
+    if (n_loc < 1 || c->cfg.n_angles % n_loc != 0) return fail(c, -3, "rr_assemble_frames_device: n_loc must divide n_angles");
+    if (n_frames < 1 || n_frames > 32) return fail(c, -3, "rr_assemble_frames_device: n_frames must be 1..32");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    { TimedScope t(c, s, "assemble"); launch_assemble_u8(d_cols_u8, d_imgs_u8, c->cfg.n_angles, c->cfg.n_cells, c->cfg.scroll_image, s, n_loc, block_stride, n_frames, frame_stride); }
     RR_HIP(c, hipGetLastError());
     return 0;
 }

@@ -764,8 +764,12 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 template <typename T>
 __global__ __launch_bounds__(256) void k_assemble(const T* __restrict__ cols, T* __restrict__ img,
                                                   int n_angles, int n_cells, int scroll,
-                                                  int n_loc, size_t block_stride)
+                                                  int n_loc, size_t block_stride, size_t frame_stride)
 {
+    // blockIdx.z = frame of a multi-frame step: its columns start frame_stride elements further,
+    // its image is the next [n_cells][n_angles] slab
+    cols += (size_t)blockIdx.z * frame_stride;
+    img += (size_t)blockIdx.z * (size_t)n_cells * n_angles;
     // azimuth a lives at cols + (a / n_loc) * block_stride + (a % n_loc) * n_cells
     // (contiguous [n_angles][n_cells] when block_stride == n_loc * n_cells)
     __shared__ T tile[64][65];
@@ -829,17 +833,18 @@ void launch_column(const Params& P, hipStream_t s)
 }
 
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
-                        int n_loc, size_t block_stride)
+                        int n_loc, size_t block_stride, int n_frames, size_t frame_stride)
 {
-    dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64), block(256);
+    dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64, n_frames > 0 ? n_frames : 1), block(256);
     if (n_loc <= 0) { n_loc = n_angles; block_stride = (size_t)n_angles * n_cells; }
-    hipLaunchKernelGGL((k_assemble<uint8_t>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll, n_loc, block_stride);
+    hipLaunchKernelGGL((k_assemble<uint8_t>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll, n_loc, block_stride,
+                       frame_stride);
 }
 
 void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s)
 {
     dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64), block(256);
-    hipLaunchKernelGGL((k_assemble<float>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll, n_angles, (size_t)n_angles * n_cells);
+    hipLaunchKernelGGL((k_assemble<float>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll, n_angles, (size_t)n_angles * n_cells, (size_t)0);
 }
 
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,

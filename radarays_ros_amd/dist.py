@@ -118,9 +118,9 @@ class AzimuthShard:
                     src = s.recv
                 else:
                     src = s.block
-                for j in range(self.fpr):
-                    self.ctx.assemble_blocks_device(src.data_ptr() + j * nl * C, nl, self.fpr * nl * C,
-                                                    s.images[j].data_ptr(), sp)
+                # all fpr frames of this rank in one launch
+                self.ctx.assemble_frames_device(src.data_ptr(), nl, self.fpr * nl * C, self.fpr, nl * C,
+                                                s.images.data_ptr(), sp)
             if s.done is not None:
                 s.done.record(s.stream)
         self.last = s

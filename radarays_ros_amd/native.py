@@ -17,7 +17,7 @@ SYMBOLS = [
     "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
     "rr_set_mesh", "rr_set_mesh_gpu", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
     "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device", "rr_simulate_batch_columns_device",
-    "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_simulate_device", "rr_synchronize", "rr_get_stats",
+    "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
     "rr_get_kernel_time",
 ]
@@ -104,6 +104,7 @@ def lib():
     L.rr_simulate_batch_columns_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.rr_assemble_image_device.argtypes = [vp, vp, vp, vp]
     L.rr_assemble_blocks_device.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, vp]
+    L.rr_assemble_frames_device.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_size_t, vp, vp]
     L.rr_simulate_device.argtypes = [vp, vp, vp, vp]
     L.rr_synchronize.argtypes = [vp, vp]
     L.rr_get_stats.argtypes = [vp, C.POINTER(RRStats)]
@@ -248,6 +249,10 @@ class Context:
 
     def assemble_blocks_device(self, d_cols_u8_ptr, n_loc, block_stride, d_img_ptr, stream=None):
         self._ck(self._L.rr_assemble_blocks_device(self._h, d_cols_u8_ptr, int(n_loc), int(block_stride), d_img_ptr, stream))
+
+    def assemble_frames_device(self, d_cols_u8_ptr, n_loc, block_stride, n_frames, frame_stride, d_imgs_ptr, stream=None):
+        self._ck(self._L.rr_assemble_frames_device(self._h, d_cols_u8_ptr, int(n_loc), int(block_stride), int(n_frames),
+                                                   int(frame_stride), d_imgs_ptr, stream))
 
     def simulate_device(self, pose, d_img_ptr, stream=None):
         p = np.ascontiguousarray(pose, np.float32)

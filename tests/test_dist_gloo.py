@@ -155,6 +155,10 @@ class _MockCtx:
     def assemble_image_device(self, ptr, img_ptr, sp):
         self.assemble_blocks_device(ptr, self.A, self.A * self.C, img_ptr, sp)
 
+    def assemble_frames_device(self, ptr, n_loc, stride, n_frames, frame_stride, imgs_ptr, sp):
+        for j in range(n_frames):
+            self.assemble_blocks_device(ptr + j * frame_stride, n_loc, stride, imgs_ptr + j * self.C * self.A, sp)
+
 
 def _worker_shard(rank, world, port, out_dir):
     """The REAL AzimuthShard step loop (weak fpr=2 and strong) on 2 gloo ranks with a mock context."""
