@@ -18,6 +18,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
 void launch_shade(const Params& P, int pass, hipStream_t s);
 void launch_scan(const Params& P, int pass, hipStream_t s);
 void launch_column(const Params& P, hipStream_t s);
+void launch_decay_table(float* decay, int n_cells, double resolution, double energy_loss, hipStream_t s);
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
                         int n_loc = 0, size_t block_stride = 0, int n_frames = 1, size_t frame_stride = 0);
 void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s);
@@ -106,7 +107,7 @@ struct rr_ctx {
     DevBuf<float4> d_qas, d_beams, d_materials;
     DevBuf<uint32_t> d_beam_order;
     DevBuf<int32_t> d_objmat;
-    DevBuf<float> d_smear, d_noise, d_motion;
+    DevBuf<float> d_smear, d_noise, d_motion, d_decay;
     bool tables_dirty = true;
 
     // frame lanes: each owns a full set of frame buffers + a stream, so consecutive
@@ -258,6 +259,11 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, c->d_smear.ensure(c->smear.size()));
     if (!c->smear.empty()) RR_HIP(c, hipMemcpy(c->d_smear.p, c->smear.data(), c->smear.size() * sizeof(float), hipMemcpyHostToDevice));
 
+    RR_HIP(c, c->d_decay.ensure((size_t)std::max(1, g.n_cells)));
+    launch_decay_table(c->d_decay.p, g.n_cells, g.resolution, g.ambient_noise_energy_loss, nullptr);
+    RR_HIP(c, hipGetLastError());
+    RR_HIP(c, hipDeviceSynchronize());
+
     std::vector<float> nz((size_t)g.n_angles, 0.0f);
     for (size_t i = 0; i < nz.size() && i < c->noise.size(); i++) nz[i] = c->noise[i];
     RR_HIP(c, c->d_noise.ensure(nz.size()));
@@ -322,6 +328,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.materials = c->d_materials.p;
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
+    P.decay = c->d_decay.p;
     P.motion_poses = c->motion.empty() ? nullptr : c->d_motion.p;
     for (int k = 0; k < 2; k++) {
         P.waves[k].A = L.d_wA[k].p; P.waves[k].B = L.d_wB[k].p; P.waves[k].C = L.d_wC[k].p;
@@ -481,7 +488,7 @@ void rr_destroy(rr_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
-    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_beam_order.release(); c->d_motion.release();
+    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_beam_order.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }

@@ -87,6 +87,7 @@ struct Params {
     const int32_t* object_materials;
     const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)
     const float* noise_rnd;      // [n_angles] or null
+    const float* decay;          // [n_cells] expf(-energy_loss * bin range), ambient noise floor
     const float* motion_poses;   // [n_angles][7] per-azimuth Tsm (include_motion) or null
     // frame state
     WaveBuf waves[2];            // [n_seg][2*cap] child slots, ping-pong by pass parity

@@ -553,25 +553,34 @@ __constant__ unsigned char c_perm[256] = {
 };
 __device__ inline double p_fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }
 __device__ inline double p_lerp(double t, double a, double b) { return a + t * (b - a); }
-__device__ inline double p_grad(int hash, double x, double y, double z)
+// grad(hash, x, y, z = 0) of image_algorithms.h:57-67 is (+-u) + (+-v) with u, v picked from
+// {x, y, 0} by the low four hash bits: a*x + b*y with a, b in {-1, 0, +1}.  Products with +-1
+// and 0 are exact and the sum has the same two operands, so this is the same f64 value (only
+// the sign of an exact zero can differ, which no later sum can see).  The (a, b) pair of
+// pt[k] & 15 is tabulated per k so one LDS read replaces the hash decode.
+__device__ inline double2 p_grad_coef(int hash)
 {
     const int h = hash & 15;
-    const double u = h < 8 ? x : y;
-    const double v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
-    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+    const double su = (h & 1) == 0 ? 1.0 : -1.0, sv = (h & 2) == 0 ? 1.0 : -1.0;
+    double a = 0.0, b = 0.0;
+    if (h < 8) a = su; else b = su;                 // u = h < 8 ? x : y
+    if (h < 4) b = sv;                              // v = h < 4 ? y : (h == 12 || h == 14 ? x : z)
+    else if (h == 12 || h == 14) a = sv;
+    return make_double2(a, b);
 }
+__device__ inline double p_grad2(const double2 g, double x, double y) { return g.x * x + g.y * y; }
 // perlin_noise(x, y, z = 0) of image_algorithms.h:69-106 with the permutation table in LDS.
 // For z = 0: Z = 0, w = fade(0) = 0, and lerp(0, a, b) = a + 0*(b - a) = a exactly (b - a is
 // finite), so the z-1 half of the lattice is not evaluated -- bit-identical result.
-__device__ inline double perlin_noise(const unsigned char* pt, double sx, double sy)
+__device__ inline double perlin_noise(const unsigned char* pt, const double2* gt, double sx, double sy)
 {
     const int X = (int)floor(sx) & 255, Y = (int)floor(sy) & 255;
-    const double x = sx - floor(sx), y = sy - floor(sy), z = 0.0;
+    const double x = sx - floor(sx), y = sy - floor(sy);
     const double u = p_fade(x), v = p_fade(y);
     const int A = pt[X] + Y, AA = pt[A & 255], AB = pt[(A + 1) & 255];
     const int B = pt[(X + 1) & 255] + Y, BA = pt[B & 255], BB = pt[(B + 1) & 255];
-    return p_lerp(v, p_lerp(u, p_grad(pt[AA], x, y, z), p_grad(pt[BA], x - 1, y, z)),
-                     p_lerp(u, p_grad(pt[AB], x, y - 1, z), p_grad(pt[BB], x - 1, y - 1, z)));
+    return p_lerp(v, p_lerp(u, p_grad2(gt[AA], x, y), p_grad2(gt[BA], x - 1, y)),
+                     p_lerp(u, p_grad2(gt[AB], x, y - 1), p_grad2(gt[BB], x - 1, y - 1)));
 }
 
 // defined variate stream for ambient_noise == 1 (the reference draws from
@@ -589,9 +598,22 @@ __device__ inline float uniform01(uint32_t seed, uint32_t col, uint32_t i)
 // cv::saturate_cast<uchar>(float): cvRound (round-half-even); NaN / out of int range -> 0
 __device__ inline uint8_t saturate_u8(float x)
 {
-    if (!(x > -2147483648.0f && x < 2147483648.0f)) return 0;
-    const float r = __builtin_rintf(x);
-    return (uint8_t)(r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r));
+    const float r = __builtin_amdgcn_fmed3f(__builtin_rintf(x), 0.0f, 255.0f);
+    return (__builtin_fabsf(x) < 2147483648.0f) ? (uint8_t)(int)r : (uint8_t)0;
+}
+
+// range decay of the ambient noise floor, one value per bin (RadarCPU.cpp:519-521)
+__global__ void k_decay_table(float* decay, int n_cells, double resolution, double energy_loss_d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    const float energy_loss = (float)energy_loss_d;
+    const float x = (float)(((double)(float)i + 0.5) * resolution);
+    decay[i] = expf(-energy_loss * x);
+}
+void launch_decay_table(float* decay, int n_cells, double resolution, double energy_loss, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decay_table, dim3((n_cells + 255) / 256), dim3(256), 0, s, decay, n_cells, resolution, energy_loss);
 }
 
 // ---------------------------------------------------------------------------
@@ -612,6 +634,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     __shared__ unsigned long long s_tiles[2];
     __shared__ float s_red[kColWaves];
     __shared__ unsigned char s_perm[256];
+    __shared__ double2 s_grad[256];
 
     const int seg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -632,7 +655,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 
     for (int i = tid; i < n_cells; i += kColThreads) lds_col[i] = 0.0f;
     if (tid < W && P.signal_denoising > 0) s_w[tid] = P.smear[tid];
-    if (tid < 256) s_perm[tid] = c_perm[tid];
+    if (tid < 256) { s_perm[tid] = c_perm[tid]; s_grad[tid] = p_grad_coef(c_perm[tid]); }
     __syncthreads();
 
     int n_valid_last = 0, n_hit_last = 0;
@@ -728,8 +751,8 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 p = (double)uniform01((uint32_t)(int)rnd, (uint32_t)col, (uint32_t)i);
             } else if (P.ambient_noise == 2) {
                 const double random_begin = (double)rnd;
-                const double p1 = perlin_noise(s_perm, random_begin + (double)i * 0.05, (double)col * 0.05);
-                const double p2 = perlin_noise(s_perm, random_begin + (double)i * 0.2, (double)col * 0.2);
+                const double p1 = perlin_noise(s_perm, s_grad, random_begin + (double)i * 0.05, (double)col * 0.05);
+                const double p2 = perlin_noise(s_perm, s_grad, random_begin + (double)i * 0.2, (double)col * 0.2);
                 p = 0.9 * p1 + 0.1 * p2;
             }
             const float signal_max = max_val;
@@ -744,10 +767,10 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
             const float noise_amp = (float)((double)(signal__ * noise_at_0) + (1.0 - (double)signal__) * (double)noise_at_1);
             const float noise_energy_max = (float)((double)signal_max * P.noise_e_max);
             const float noise_energy_min = (float)((double)signal_max * P.noise_e_min);
-            const float energy_loss = (float)P.noise_e_loss;
             float y_noise = (float)((double)noise_amp * p);
-            const float x = (float)(((double)(float)i + 0.5) * P.resolution);
-            y_noise = y_noise + (noise_energy_max - noise_energy_min) * expf(-energy_loss * x) + noise_energy_min;
+            // expf(-energy_loss * x) with x = (float)((i + 0.5) * resolution) (RadarCPU.cpp:519-521)
+            // depends on the bin only: tabulated by k_decay_table with the same arithmetic
+            y_noise = y_noise + (noise_energy_max - noise_energy_min) * P.decay[i] + noise_energy_min;
             y_noise = fabsf(y_noise);
             v = signal + y_noise;
         }
