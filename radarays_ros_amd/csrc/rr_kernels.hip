@@ -812,6 +812,52 @@ __global__ __launch_bounds__(256) void k_assemble(const T* __restrict__ cols, T*
     }
 }
 
+// mono8 fast path: four bins per load, four azimuths per store.  Needs n_cells % 4 == 0,
+// n_angles % 4 == 0, scroll % 4 == 0 (a group of four azimuths then never straddles the
+// wrap), n_loc % 4 == 0 is NOT needed (rows are addressed one by one).  Divisions by n_loc
+// are multiplications by `magic` = floor(2^32 / n_loc) + 1, exact for a < 65536.
+// grid (ceil(n_cells/64), ceil(n_angles/64), n_frames), block 256
+__global__ __launch_bounds__(256) void k_assemble_u8x4(const uint8_t* __restrict__ cols, uint8_t* __restrict__ img,
+                                                       int n_angles, int n_cells, int scroll,
+                                                       int n_loc, uint32_t magic, size_t block_stride, size_t frame_stride)
+{
+    cols += (size_t)blockIdx.z * frame_stride;
+    img += (size_t)blockIdx.z * (size_t)n_cells * n_angles;
+    __shared__ uint32_t tile[64][17];              // [azimuth][16 words of 4 bins] + 1 pad
+    const int c0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+    {
+        const int w = t & 15, c = c0 + 4 * w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = (t >> 4) + 16 * k, a = a0 + r;
+            uint32_t v = 0;
+            if (a < n_angles && c < n_cells) {
+                const uint32_t blk = __umulhi((uint32_t)a, magic);
+                const uint32_t loc = (uint32_t)a - blk * (uint32_t)n_loc;
+                v = *reinterpret_cast<const uint32_t*>(cols + (size_t)blk * block_stride + (size_t)loc * n_cells + c);
+            }
+            tile[r][w] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int g = t & 15, a = a0 + 4 * g;      // group of four azimuths
+        int col = scroll + a;
+        if (col >= n_angles) col -= n_angles;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = (t >> 4) + 16 * k, c = c0 + r;   // bin row of the tile
+            if (a < n_angles && c < n_cells) {
+                const int w = r >> 2, sh = 8 * (r & 3);
+                const uint32_t b0 = (tile[4 * g + 0][w] >> sh) & 0xFFu, b1 = (tile[4 * g + 1][w] >> sh) & 0xFFu;
+                const uint32_t b2 = (tile[4 * g + 2][w] >> sh) & 0xFFu, b3 = (tile[4 * g + 3][w] >> sh) & 0xFFu;
+                *reinterpret_cast<uint32_t*>(img + (size_t)c * n_angles + col) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers (called from rr_api.cpp through plain C++ prototypes)
 // ---------------------------------------------------------------------------
@@ -860,6 +906,14 @@ void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_c
 {
     dim3 grid((n_cells + 63) / 64, (n_angles + 63) / 64, n_frames > 0 ? n_frames : 1), block(256);
     if (n_loc <= 0) { n_loc = n_angles; block_stride = (size_t)n_angles * n_cells; }
+    const int sc = ((scroll % n_angles) + n_angles) % n_angles;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(cols) | reinterpret_cast<uintptr_t>(img) | block_stride | frame_stride) & 3u) == 0;
+    if (aligned && n_cells % 4 == 0 && n_angles % 4 == 0 && sc % 4 == 0 && n_angles < 65536 && n_loc > 1) {
+        const uint32_t magic = (uint32_t)((1ull << 32) / (uint32_t)n_loc) + 1u;
+        hipLaunchKernelGGL(k_assemble_u8x4, grid, block, 0, s, cols, img, n_angles, n_cells, sc, n_loc, magic,
+                           block_stride, frame_stride);
+        return;
+    }
     hipLaunchKernelGGL((k_assemble<uint8_t>), grid, block, 0, s, cols, img, n_angles, n_cells, scroll, n_loc, block_stride,
                        frame_stride);
 }

@@ -433,3 +433,36 @@ def test_gpu_bvh_builder_gives_identical_images(native_lib):
     t, f = c.debug_trace(np.float32([[0.2, 0.2, 0]]), np.float32([[0, 0, 1]]))
     assert t[0] == 5.0 and f[0] == 0                                                # lowest face id wins the tie
     c.close()
+
+
+@pytest.mark.parametrize("n_cells", [3424, 1000, 250])
+def test_assemble_matches_numpy(native_lib, n_cells):
+    """rr_assemble_{image,blocks,frames}_device against a numpy transpose: scroll values that take the
+    four-azimuth fast path (multiples of 4) and the byte path, column blocks as an all-to-all delivers
+    them ([source rank][frame][n_loc][n_cells]), several frames in one launch."""
+    import torch
+    s = scenes.box12()
+    rs = np.random.RandomState(5)
+    for scroll in (0, 4, 100, 396, 3, 399):
+        cfg = params.kaist_preset(n_reflections=1, ambient_noise=0, scroll_image=scroll, n_cells=n_cells)
+        c = _ctx(native_lib, s, cfg, materials_for(s), golden_beams(8))
+        st = torch.cuda.current_stream().cuda_stream
+        for world, fpr in ((1, 1), (2, 3), (4, 2), (8, 1)):
+            nl = 400 // world
+            blocks = rs.randint(0, 256, (world, fpr, nl, n_cells)).astype(np.uint8)
+            d_blocks = torch.from_numpy(blocks).cuda()
+            d_imgs = torch.zeros((fpr, n_cells, 400), dtype=torch.uint8, device="cuda:0")
+            d_one = torch.zeros((n_cells, 400), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()     # stream 0 = the context's own stream: the fills must have landed
+            c.assemble_frames_device(d_blocks.data_ptr(), nl, fpr * nl * n_cells, fpr, nl * n_cells, d_imgs.data_ptr(), st)
+            torch.cuda.synchronize()
+            got = d_imgs.cpu().numpy()
+            for j in range(fpr):
+                cols = blocks[:, j].reshape(400, n_cells)            # [azimuth][bin]
+                want = np.zeros((n_cells, 400), np.uint8)
+                want[:, (scroll + np.arange(400)) % 400] = cols.T
+                assert np.array_equal(got[j], want), (scroll, world, fpr, j)
+            c.assemble_blocks_device(d_blocks.data_ptr(), nl, fpr * nl * n_cells, d_one.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_one.cpu().numpy(), got[0])
+        c.close()
