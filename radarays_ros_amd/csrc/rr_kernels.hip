@@ -67,9 +67,24 @@ constexpr int kRaysPerBlock = kTraceThreads / 4;
 #define RR_QXOR1 0xB1
 #define RR_QXOR2 0x4E
 
+// A ray prepared for the slab test: 1/d with tiny components clamped so it stays finite, and
+// oo = -o/d, so that (plane - o)/d is one fma.
+struct RaySetup { V3 o, d; float idx, idy, idz, oox, ooy, ooz; };
+__device__ inline RaySetup ray_setup(V3 o, V3 d)
+{
+    RaySetup R; R.o = o; R.d = d;
+    const float eps = 1e-20f;
+    const float dx = fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x;
+    const float dy = fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y;
+    const float dz = fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z;
+    R.idx = 1.0f / dx; R.idy = 1.0f / dy; R.idz = 1.0f / dz;
+    R.oox = -o.x * R.idx; R.ooy = -o.y * R.idy; R.ooz = -o.z * R.idz;
+    return R;
+}
+
 template <bool STATS, bool SPILL>
 __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris,
-                               V3 o, V3 d, float range_max,
+                               const RaySetup& R, float range_max,
                                uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gray,
                                unsigned& n_nodes, unsigned& n_tris)
 {
@@ -77,13 +92,8 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     const int wave = threadIdx.x >> 6;
     const int rw = (threadIdx.x & 63) >> 2;                         // ray within the wave
     uint32_t* my = lds_stack + (size_t)wave * stack_lds * kRaysPerWave + rw;   // entry e at my[e*16]
-    // clamp tiny direction components so 1/d stays finite (slab test only)
-    const float eps = 1e-20f;
-    const float dx = fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x;
-    const float dy = fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y;
-    const float dz = fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z;
-    const float idx = 1.0f / dx, idy = 1.0f / dy, idz = 1.0f / dz;
-    const float oox = -o.x * idx, ooy = -o.y * idy, ooz = -o.z * idz;
+    const V3 o = R.o, d = R.d;
+    const float idx = R.idx, idy = R.idy, idz = R.idz, oox = R.oox, ooy = R.ooy, ooz = R.ooz;
 
     Hit best; best.t = __builtin_inff(); best.tri = 0xFFFFFFFFu; best.face = 0xFFFFFFFFu;
     float tcull = range_max * 1.0001f + 1e-3f;
@@ -179,41 +189,57 @@ template <bool FIRST, bool STATS, bool SPILL>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
 {
     extern __shared__ uint32_t lds_stack[];
+    // prepared rays of the workgroup, one per lane of wave 0 (a quad would otherwise repeat the
+    // pose algebra four times and every wave would issue it for just 16 rays)
+    __shared__ float s_ray[12][kRaysPerBlock];
+    __shared__ int s_j[kRaysPerBlock];
     const int seg = blockIdx.y;
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-    const int k = blockIdx.x * kRaysPerBlock + r;      // trace slot
     const int cur = pass & 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
     if ((int)(blockIdx.x * kRaysPerBlock) >= count) return;
-    const bool active = k < count;
-    // pass 0 is traced in a spatially sorted order of the beam samples; results are
-    // stored under the wave's own index j, so the reference order is untouched
-    int j = k;
-    if (active) j = FIRST ? (int)P.beam_order[k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
-
-    V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
-    if (active) {
-        if (FIRST) {
-            const float4 b = P.beams[j];
-            dir = { b.x, b.y, b.z };
-        } else {
-            const uint32_t slot = P.idx[cur][(size_t)seg * P.cap + j];
-            const size_t w = (size_t)seg * 2 * P.cap + slot;
-            const float4 A = P.waves[cur].A[w], B = P.waves[cur].B[w];
-            orig = { A.x, A.y, A.z };
-            dir = { A.w, B.x, B.y };
+    if (threadIdx.x < kRaysPerBlock) {
+        const int rr = threadIdx.x;
+        const int k = blockIdx.x * kRaysPerBlock + rr;     // trace slot
+        // pass 0 is traced in a spatially sorted order of the beam samples; results are
+        // stored under the wave's own index j, so the reference order is untouched
+        int j = -1;
+        V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
+        if (k < count) {
+            j = FIRST ? (int)P.beam_order[k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
+            if (FIRST) {
+                const float4 b = P.beams[j];
+                dir = { b.x, b.y, b.z };
+            } else {
+                const uint32_t slot = P.idx[cur][(size_t)seg * P.cap + j];
+                const size_t w = (size_t)seg * 2 * P.cap + slot;
+                const float4 A = P.waves[cur].A[w], B = P.waves[cur].B[w];
+                orig = { A.x, A.y, A.z };
+                dir = { A.w, B.x, B.y };
+            }
         }
+        Quat q_am; V3 t_am;
+        azimuth_frame(P, seg, q_am, t_am);
+        const RaySetup R = ray_setup(v_add(q_rot(q_am, orig), t_am), q_rot(q_am, dir));
+        s_ray[0][rr] = R.o.x; s_ray[1][rr] = R.o.y; s_ray[2][rr] = R.o.z;
+        s_ray[3][rr] = R.d.x; s_ray[4][rr] = R.d.y; s_ray[5][rr] = R.d.z;
+        s_ray[6][rr] = R.idx; s_ray[7][rr] = R.idy; s_ray[8][rr] = R.idz;
+        s_ray[9][rr] = R.oox; s_ray[10][rr] = R.ooy; s_ray[11][rr] = R.ooz;
+        s_j[rr] = j;
     }
-    Quat q_am; V3 t_am;
-    azimuth_frame(P, seg, q_am, t_am);
-    const V3 o_m = v_add(q_rot(q_am, orig), t_am);
-    const V3 d_m = q_rot(q_am, dir);
+    __syncthreads();
+    const int j = s_j[r];
+    const bool active = j >= 0;
 
     unsigned nn = 0, nt = 0;
     if (active) {
+        RaySetup R;
+        R.o = { s_ray[0][r], s_ray[1][r], s_ray[2][r] }; R.d = { s_ray[3][r], s_ray[4][r], s_ray[5][r] };
+        R.idx = s_ray[6][r]; R.idy = s_ray[7][r]; R.idz = s_ray[8][r];
+        R.oox = s_ray[9][r]; R.ooy = s_ray[10][r]; R.ooz = s_ray[11][r];
         const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
-        const Hit h = traverse<STATS, SPILL>(P.nodes, P.tris, o_m, d_m, P.range_max, lds_stack, P.stack_lds,
+        const Hit h = traverse<STATS, SPILL>(P.nodes, P.tris, R, P.range_max, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
@@ -244,7 +270,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, c
     const V3 o = { origs[3 * i], origs[3 * i + 1], origs[3 * i + 2] };
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
-    const Hit h = traverse<false, true>(P.nodes, P.tris, o, d, P.range_max, lds_stack, P.stack_lds,
+    const RaySetup R = ray_setup(o, d);
+    const Hit h = traverse<false, true>(P.nodes, P.tris, R, P.range_max, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
     if ((threadIdx.x & 3) == 0) {
         out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradarays_mi355.so")
+LIB_PATH = os.environ.get("RADARAYS_MI355_LIB") or os.path.join(_HERE, "libradarays_mi355.so")
 _LIB = None
 
 SYMBOLS = [
