@@ -64,6 +64,10 @@ constexpr int kRaysPerBlock = kTraceThreads / 4;
 #define RR_QBCAST1 0x55
 #define RR_QBCAST2 0xAA
 #define RR_QBCAST3 0xFF
+// rotations: lane q reads lane (q + k) & 3
+#define RR_QROT1 0x39
+#define RR_QROT2 0x4E
+#define RR_QROT3 0x93
 #define RR_QXOR1 0xB1
 #define RR_QXOR2 0x4E
 
@@ -96,6 +100,7 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     const float idx = R.idx, idy = R.idy, idz = R.idz, oox = R.oox, ooy = R.ooy, ooz = R.ooz;
 
     Hit best; best.t = __builtin_inff(); best.tri = 0xFFFFFFFFu; best.face = 0xFFFFFFFFu;
+    unsigned long long bestkey = 0x7F800000FFFFFFFFull;   // (+inf : no face)
     float tcull = range_max * 1.0001f + 1e-3f;
     int sp = 0;
     uint32_t cur = 0;   // root
@@ -103,6 +108,8 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     const float4* node4 = reinterpret_cast<const float4*>(nodes);   // 8 float4 per node, 2 per child
     const float4* tri4 = reinterpret_cast<const float4*>(tris);     // 3 float4 per triangle
     const int qsh = (threadIdx.x & 63) & ~3;                        // bit position of this quad in a ballot
+    uint32_t misskey = 0x7F800000u | (uint32_t)q;                   // key of a missed child
+    asm volatile("" : "+v"(misskey));                              // opaque: keeps (tmin & ~3) | q one v_and_or_b32
     while (true) {
         // ---- ONE batch of loads per step, whatever the step is (single s_waitcnt) ----
         const bool leaf = (cur & kLeafFlag) != 0;
@@ -120,15 +127,22 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
             const float az = __builtin_fmaf(A.z, idz, ooz), bz = __builtin_fmaf(B.y, idz, ooz);
             const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
             const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
-            const bool h = (tmin <= tmax) && (tmin <= tcull);
+            // tmin <= min(tmax, tcull) as ONE compare (its mask is the ballot below).  tcull >= 0, so the
+            // signed-integer minimum of the two bit patterns is the float minimum whenever tmax >= 0 and
+            // a negative value (-> no hit, tmin >= 0) whenever tmax < 0
+            const float lim = __int_as_float(min(__float_as_int(tmax), __float_as_int(tcull)));
+            const bool h = tmin <= lim;
             // distinct keys (lane id in the low bits); a miss sorts last
-            const uint32_t mykey = h ? ((__float_as_uint(tmin) & ~3u) | (uint32_t)q) : (0x7F800000u | (uint32_t)q);
+            const uint32_t mykey = h ? ((__float_as_uint(tmin) & ~3u) | (uint32_t)q) : misskey;
             const uint32_t myref = __float_as_uint(B.z);
-            const uint32_t k0 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST0), k1 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST1);
-            const uint32_t k2 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST2), k3 = (uint32_t)RR_DPP_I(mykey, RR_QBCAST3);
-            // rank of my child among the four (0 = nearest); number of hit children of the quad
-            const int rank = (int)(k0 < mykey) + (int)(k1 < mykey) + (int)(k2 < mykey) + (int)(k3 < mykey);
-            const int nhit = __builtin_popcount((unsigned)(__ballot(h) >> qsh) & 0xFu);
+            // rank of my child among the four (0 = nearest): the three other keys arrive by quad
+            // rotations; keys are < 2^31, so the sign of (other - mine) says "other is nearer"
+            const uint32_t d1 = (uint32_t)RR_DPP_I(mykey, RR_QROT1) - mykey;
+            const uint32_t d2 = (uint32_t)RR_DPP_I(mykey, RR_QROT2) - mykey;
+            const uint32_t d3 = (uint32_t)RR_DPP_I(mykey, RR_QROT3) - mykey;
+            const int rank = (int)((d1 >> 31) + (d2 >> 31) + (d3 >> 31));
+            // number of hit children of the quad
+            const int nhit = __builtin_popcount((unsigned)(__builtin_amdgcn_ballot_w64(h) >> qsh) & 0xFu);
             // nearest child -> cur (OR-reduce over the quad); the others go on the stack far-first,
             // each lane storing its OWN reference: no sorted copies of the refs are needed
             uint32_t nxt = (h && rank == 0) ? myref : 0u;
@@ -159,20 +173,24 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
                                 (tt > 0.0f && tt <= range_max);
                 if (ok) { t = tt; face = __float_as_uint(A.w); tri = first + q; }
             }
-            // quad-wide nearest (t, then lower face index)
+            // quad-wide nearest (t, then lower face index): t is positive or +inf, so the order of
+            // (t, face) is the unsigned order of the 64-bit word (t bits : face)
+            unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | face;
             {
-                float t2 = RR_DPP_F(t, RR_QXOR1);
-                uint32_t f2 = (uint32_t)RR_DPP_I(face, RR_QXOR1), r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR1);
-                bool take = (t2 < t) || (t2 == t && f2 < face);
-                t = take ? t2 : t; face = take ? f2 : face; tri = take ? r2 : tri;
-                t2 = RR_DPP_F(t, RR_QXOR2);
-                f2 = (uint32_t)RR_DPP_I(face, RR_QXOR2); r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR2);
-                take = (t2 < t) || (t2 == t && f2 < face);
-                t = take ? t2 : t; face = take ? f2 : face; tri = take ? r2 : tri;
+                unsigned long long k2 = ((unsigned long long)(uint32_t)RR_DPP_I((uint32_t)(key >> 32), RR_QXOR1) << 32) |
+                                        (uint32_t)RR_DPP_I((uint32_t)key, RR_QXOR1);
+                uint32_t r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR1);
+                bool take = k2 < key;
+                key = take ? k2 : key; tri = take ? r2 : tri;
+                k2 = ((unsigned long long)(uint32_t)RR_DPP_I((uint32_t)(key >> 32), RR_QXOR2) << 32) |
+                     (uint32_t)RR_DPP_I((uint32_t)key, RR_QXOR2);
+                r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR2);
+                take = k2 < key;
+                key = take ? k2 : key; tri = take ? r2 : tri;
             }
-            if (t < best.t || (t == best.t && face < best.face)) {
-                best.t = t; best.tri = tri; best.face = face;
-                tcull = t * 1.0001f + 1e-3f;
+            if (key < bestkey) {
+                bestkey = key; best.tri = tri;
+                tcull = __uint_as_float((uint32_t)(key >> 32)) * 1.0001f + 1e-3f;
             }
         }
         // pop
@@ -181,6 +199,7 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
         sp--;
         cur = (SPILL && sp >= stack_lds) ? spill[(size_t)(sp - stack_lds) * spill_stride + gray] : my[sp * kRaysPerWave];
     }
+    best.t = __uint_as_float((uint32_t)(bestkey >> 32)); best.face = (uint32_t)bestkey;
     return best;
 }
 
