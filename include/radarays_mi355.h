@@ -171,6 +171,21 @@ int rr_assemble_image_device(rr_ctx* ctx, const uint8_t* d_cols_u8 /*[n_angles][
 int rr_assemble_blocks_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
                               uint8_t* d_img_u8, void* stream);
 
+/* Parameter batch: n_sets (1..32) material tables, ONE pose -> n_sets images.
+ * Replaces n_sets round trips of the reference's optimisation loop, where every objective
+ * evaluation sends one RadarParams goal to the gen_radar_image action and waits for one image
+ * (action/GenRadarImage.action, scripts/radaray_opti.py:170-200; the server side sets
+ * m_params.materials and calls simulate(), Radar.hpp:52-53).  `sets` is [n_sets][n_materials]
+ * with n_materials as given to rr_set_materials (object -> material map, air id, config and beam
+ * samples stay as set).  Pass 0 does not depend on the materials and is traced once for all sets;
+ * image k is bit-identical to rr_set_materials(sets[k]) + rr_simulate_device(pose).
+ * d_imgs_u8: [n_sets][n_cells][n_angles] in HBM, stream-ordered like rr_simulate_device. */
+int rr_simulate_material_sets_device(rr_ctx* ctx, const float pose[7], const rr_material* sets, int n_sets,
+                                     uint8_t* d_imgs_u8, void* stream);
+/* Same with a host output buffer (synchronous). */
+int rr_simulate_material_sets(rr_ctx* ctx, const float pose[7], const rr_material* sets, int n_sets,
+                              uint8_t* out_imgs_u8);
+
 /* All frames of a multi-frame step in ONE launch: frame j reads its columns frame_stride bytes after
  * frame j-1 (block addressing as above) and writes image j of d_imgs_u8 [n_frames][n_cells][n_angles]. */
 int rr_assemble_frames_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,

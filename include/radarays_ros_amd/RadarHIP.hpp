@@ -127,7 +127,50 @@ public:
             std::cout << "Couldn't get Transform between sensor and map. Skipping..." << std::endl;   // RadarCPU.cpp:131
             return msg;
         }
-        if (m_resample || m_waves_start.empty()) { m_err = "beam samples not set (setBeamSamples)"; return msg; }
+        if (!push()) return msg;
+        msg = std::make_shared<Image>();
+        msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;
+        msg->data.assign((size_t)msg->height * msg->width, 0);
+        if (rr_simulate(m_ctx, Tsm_last, 0, m_n_angles, msg->data.data(), nullptr, &m_stats)) { msg.reset(); return fail(); }
+        msg->stamp = stamp; msg->frame_id = m_sensor_frame;   // RadarCPU.cpp:560-561
+        return msg;
+    }
+    // The gen_radar_image action of the optimisation loop (action/GenRadarImage.action,
+    // scripts/radaray_opti.py:170-200), batched: one image per material table, same pose, one call.
+    std::vector<ImagePtr> simulateMaterialSets(const std::vector<std::vector<RadarMaterial>>& sets, double stamp)
+    {
+        std::vector<ImagePtr> out;
+        if (!updateTsm()) {
+            std::cout << "Couldn't get Transform between sensor and map. Skipping..." << std::endl;
+            return out;
+        }
+        if (!push()) return out;
+        const size_t n_mat = m_params.materials.size();
+        std::vector<rr_material> flat;
+        for (const auto& set : sets) {
+            if (set.size() != n_mat) { m_err = "every material set needs as many entries as loadParams() gave"; return out; }
+            for (const RadarMaterial& m : set) flat.push_back({ m.velocity, m.ambient, m.diffuse, m.specular });
+        }
+        const size_t npx = (size_t)m_cfg.n_cells * m_n_angles;
+        std::vector<uint8_t> px(sets.size() * npx);
+        if (rr_simulate_material_sets(m_ctx, Tsm_last, flat.data(), (int)sets.size(), px.data())) { fail(); return out; }
+        for (size_t k = 0; k < sets.size(); k++) {
+            ImagePtr msg = std::make_shared<Image>();
+            msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;
+            msg->data.assign(px.begin() + k * npx, px.begin() + (k + 1) * npx);
+            msg->stamp = stamp; msg->frame_id = m_sensor_frame;
+            out.push_back(msg);
+        }
+        return out;
+    }
+    const std::string& lastError() const { return m_err; }
+    const rr_stats& lastStats() const { return m_stats; }
+
+private:
+    // marshal the protected state of Radar into the context (what simulate() reads, Radar.hpp:66-105)
+    bool push()
+    {
+        if (m_resample || m_waves_start.empty()) { m_err = "beam samples not set (setBeamSamples)"; return false; }
         if (m_dirty_cfg) {
             rr_config c; rr_default_config(&c);
             c.n_cells = m_cfg.n_cells; c.n_reflections = (int)m_params.model.n_reflections;
@@ -148,7 +191,7 @@ public:
             c.ambient_noise_energy_min = m_cfg.ambient_noise_energy_min;
             c.ambient_noise_energy_loss = m_cfg.ambient_noise_energy_loss;
             c.wave_energy_threshold = m_wave_energy_threshold;
-            if (rr_set_config(m_ctx, &c)) return fail();
+            if (rr_set_config(m_ctx, &c)) { fail(); return false; }
             m_n_angles = c.n_angles; m_dirty_cfg = false;
         }
         if (m_dirty_mat) {
@@ -158,24 +201,15 @@ public:
                 mats[i] = { m.velocity, m.ambient, m.diffuse, m.specular };
             }
             std::vector<int32_t> om(m_object_materials.begin(), m_object_materials.end());
-            if (rr_set_materials(m_ctx, mats.data(), mats.size(), om.data(), om.size(), m_material_id_air)) return fail();
+            if (rr_set_materials(m_ctx, mats.data(), mats.size(), om.data(), om.size(), m_material_id_air)) { fail(); return false; }
             m_dirty_mat = false;
         }
         if (m_push_beams) {
-            if (rr_set_beam_samples(m_ctx, m_waves_start.data(), m_waves_start.size() / 3)) return fail();
+            if (rr_set_beam_samples(m_ctx, m_waves_start.data(), m_waves_start.size() / 3)) { fail(); return false; }
             m_push_beams = false;
         }
-        msg = std::make_shared<Image>();
-        msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;
-        msg->data.assign((size_t)msg->height * msg->width, 0);
-        if (rr_simulate(m_ctx, Tsm_last, 0, m_n_angles, msg->data.data(), nullptr, &m_stats)) { msg.reset(); return fail(); }
-        msg->stamp = stamp; msg->frame_id = m_sensor_frame;   // RadarCPU.cpp:560-561
-        return msg;
+        return true;
     }
-    const std::string& lastError() const { return m_err; }
-    const rr_stats& lastStats() const { return m_stats; }
-
-private:
     ImagePtr fail() { m_err = rr_last_error(m_ctx); std::cout << "[RadarHIP] " << m_err << std::endl; return {}; }
     rr_ctx* m_ctx = nullptr;
     int m_n_angles = 400;

@@ -71,6 +71,7 @@ struct Lane {
     DevBuf<uint8_t> d_img_u8;     // host-buffer path: assembled image before the D2H copy
     DevBuf<float> d_img_f32;
     DevBuf<SegStats> d_seg_stats;
+    DevBuf<float4> d_matsets;     // material sets of a parameter batch [n_sets][n_materials]
     int last_n_seg = 0, last_n_passes = 0;
     int spill_stride = 0, stack_lds = 1;
 
@@ -108,6 +109,7 @@ struct rr_ctx {
     DevBuf<uint32_t> d_beam_order;
     DevBuf<int32_t> d_objmat;
     DevBuf<float> d_smear, d_noise, d_motion, d_decay;
+    DevBuf<uint8_t> d_param_imgs;   // rr_simulate_material_sets: images before the D2H copy
     bool tables_dirty = true;
 
     // frame lanes: each owns a full set of frame buffers + a stream, so consecutive
@@ -383,7 +385,8 @@ int check_ready(rr_ctx* c)
 }
 
 int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
-              uint8_t* d_cols_u8, float* d_cols_f32, hipStream_t s, int n_frames = 1)
+              uint8_t* d_cols_u8, float* d_cols_f32, hipStream_t s, int n_frames = 1,
+              const float4* d_matsets = nullptr, int mat_stride = 0)
 {
     const rr_config& g = c->cfg;
     if (az_begin < 0 || az_end > g.n_angles || az_begin > az_end) return fail(c, -3, "azimuth range out of bounds");
@@ -391,7 +394,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     const int n_seg = n_loc * n_frames;
     if (n_seg == 0) return 0;
     if (n_frames < 1 || n_frames > 32) return fail(c, -3, "frame batch must be 1..32");
-    for (int k = 0; k < 7 * n_frames; k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
+    for (int k = 0; k < 7 * (d_matsets ? 1 : n_frames); k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
     int rc = upload_tables(c); if (rc) return rc;
     const int n_beam = (int)(c->beams.size() / 3);
     const int cap = wave_capacity(g, n_beam);
@@ -402,6 +405,10 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     Params P;
     fill_params(c, L, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
     P.n_loc = n_loc; P.n_frames = n_frames;
+    if (d_matsets) {   // parameter batch: one pose, one material table per frame
+        P.materials = d_matsets; P.mat_stride = mat_stride; P.share_first = 1;
+        for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[k];
+    } else
     for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[7 * f + k];
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
     L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
@@ -488,13 +495,13 @@ void rr_destroy(rr_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
-    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_beam_order.release(); c->d_motion.release();
+    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
         L.d_refpos.release();
         L.d_hit_tri.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
-        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_seg_stats.release(); L.d_img_u8.release(); L.d_img_f32.release();
+        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -645,6 +652,62 @@ int rr_simulate_batch_columns_device(rr_ctx* c, const float* poses, int n_frames
     rc = run_frame(c, L, poses, az_begin, az_end, d_cols_u8, nullptr, s, n_frames); if (rc) return rc;
     RR_HIP(c, hipEventRecord(L.ev_consumed, s));
     L.pending_consume = true;
+    return 0;
+}
+
+int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets,
+                                     uint8_t* d_imgs_u8, void* stream)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!pose || !sets || !d_imgs_u8) return fail(c, -3, "rr_simulate_material_sets_device: null pose/sets/output");
+    if (n_sets < 1 || n_sets > 32) return fail(c, -3, "rr_simulate_material_sets_device: n_sets must be 1..32");
+    const size_t n_mat = c->materials.size();
+    for (size_t i = 0; i < (size_t)n_sets * n_mat; i++)
+        if (!std::isfinite(sets[i].velocity) || !std::isfinite(sets[i].ambient) || !std::isfinite(sets[i].diffuse) ||
+            !std::isfinite(sets[i].specular))
+            return fail(c, -3, "rr_simulate_material_sets_device: non-finite material parameter");
+    RR_HIP(c, hipSetDevice(c->device));
+    const rr_config& g = c->cfg;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = upload_tables(c); if (rc) return rc;
+    const size_t li = c->next_lane++ % c->lanes.size();
+    Lane& L = c->lanes[li];
+    c->last_lane = li;
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
+    static_assert(sizeof(rr_material) == sizeof(float4), "rr_material is {velocity, ambient, diffuse, specular}");
+    if (L.d_matsets.n < (size_t)n_sets * n_mat || L.d_cols_u8.n < (size_t)n_sets * g.n_angles * g.n_cells ||
+        L.buf_seg < n_sets * g.n_angles) {
+        RR_HIP(c, hipDeviceSynchronize());      // buffers of this lane may still be read by an earlier step
+        RR_HIP(c, L.d_matsets.ensure((size_t)n_sets * n_mat));
+        rc = ensure_frame_buffers(c, L, std::max(n_sets * g.n_angles, L.buf_seg), false); if (rc) return rc;
+    }
+    // pageable source: the copy is staged before the call returns, the caller's array is free again
+    RR_HIP(c, hipMemcpyAsync(L.d_matsets.p, sets, (size_t)n_sets * n_mat * sizeof(float4), hipMemcpyHostToDevice, s));
+    rc = run_frame(c, L, pose, 0, g.n_angles, L.d_cols_u8.p, nullptr, s, n_sets, L.d_matsets.p, (int)n_mat); if (rc) return rc;
+    { TimedScope t(c, s, "assemble");
+      launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
+                         (size_t)g.n_angles * g.n_cells, n_sets, (size_t)g.n_angles * g.n_cells); }
+    RR_HIP(c, hipGetLastError());
+    RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+    L.pending_consume = true;
+    return 0;
+}
+
+int rr_simulate_material_sets(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets, uint8_t* out_imgs_u8)
+{
+    if (!c) return -1;
+    if (!out_imgs_u8) return fail(c, -3, "rr_simulate_material_sets: null output");
+    if (n_sets < 1 || n_sets > 32) return fail(c, -3, "rr_simulate_material_sets: n_sets must be 1..32");
+    RR_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n_sets * c->cfg.n_cells * c->cfg.n_angles;
+    RR_HIP(c, c->d_param_imgs.ensure(bytes));
+    int rc = rr_simulate_material_sets_device(c, pose, sets, n_sets, c->d_param_imgs.p, c->stream); if (rc) return rc;
+    RR_HIP(c, hipMemcpyAsync(out_imgs_u8, c->d_param_imgs.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    RR_HIP(c, hipStreamSynchronize(c->stream));
+    Counters h;
+    RR_HIP(c, hipMemcpy(&h, c->lanes[c->last_lane].d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
+    if (h.overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
     return 0;
 }
 

@@ -87,6 +87,8 @@ struct Params {
     const int32_t* object_materials;
     const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)
     const float* noise_rnd;      // [n_angles] or null
+    int mat_stride;              // material sets: frame f shades with materials[f * mat_stride + id] (0: one table)
+    int share_first;             // material sets: every frame has the pose of frame 0, pass 0 is traced once
     const float* decay;          // [n_cells] expf(-energy_loss * bin range), ambient noise floor
     const float* motion_poses;   // [n_angles][7] per-azimuth Tsm (include_motion) or null
     // frame state

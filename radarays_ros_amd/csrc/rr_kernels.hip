@@ -403,11 +403,13 @@ __global__ __launch_bounds__(256) void k_shade(const Params P, const int pass)
     uint8_t f0 = 0, f1 = 0;
     SigRec sg0 = { -1, 0.0f }, sg1 = { -1, 0.0f };
 
-    const float range = P.hit_t[(size_t)seg * P.cap + j];
+    // material sets: all frames share the rays of pass 0, traced once for frame 0
+    const size_t hk = (size_t)((FIRST && P.share_first) ? seg % P.n_loc : seg) * P.cap + j;
+    const float range = P.hit_t[hk];
     if (range >= 0.0f)   // miss => the wave dies silently (RadarCPU.cpp:252-255)
     {
         f0 |= 4;
-        const uint32_t tri = P.hit_tri[(size_t)seg * P.cap + j];
+        const uint32_t tri = P.hit_tri[hk];
         const float4* tp = reinterpret_cast<const float4*>(P.tris + tri);
         const float4 tb = tp[1], tc = tp[2];
         const uint32_t obj_id = __float_as_uint(tb.w);
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void k_shade(const Params P, const int pass)
         if (!ok) {
             atomicOr(&P.counters->overflow, 2u);
         } else {
-            const float4 m = P.materials[mat_refr];
+            const float4 m = P.materials[(size_t)(seg / P.n_loc) * P.mat_stride + mat_refr];
             const float v_refraction = (mat != mat_refr) ? m.x : (float)0.3;
 
             V3 rdir, tdir; double renergy, tenergy;
@@ -910,7 +912,8 @@ __global__ __launch_bounds__(256) void k_assemble_u8x4(const uint8_t* __restrict
 void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int cap_p = pass == 0 ? P.n_beam : P.cap;
-    dim3 grid((cap_p + kRaysPerBlock - 1) / kRaysPerBlock, P.n_seg), block(kTraceThreads);
+    const int n_seg = (pass == 0 && P.share_first) ? P.n_loc : P.n_seg;
+    dim3 grid((cap_p + kRaysPerBlock - 1) / kRaysPerBlock, n_seg), block(kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what

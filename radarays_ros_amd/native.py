@@ -17,7 +17,8 @@ SYMBOLS = [
     "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
     "rr_set_mesh", "rr_set_mesh_gpu", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
     "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device", "rr_simulate_batch_columns_device",
-    "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device", "rr_synchronize", "rr_get_stats",
+    "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
+    "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
     "rr_get_kernel_time",
 ]
@@ -106,6 +107,8 @@ def lib():
     L.rr_assemble_blocks_device.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, vp]
     L.rr_assemble_frames_device.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_size_t, vp, vp]
     L.rr_simulate_device.argtypes = [vp, vp, vp, vp]
+    L.rr_simulate_material_sets_device.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    L.rr_simulate_material_sets.argtypes = [vp, vp, vp, C.c_int, vp]
     L.rr_synchronize.argtypes = [vp, vp]
     L.rr_get_stats.argtypes = [vp, C.POINTER(RRStats)]
     L.rr_set_stats_mode.argtypes = [vp, C.c_int]
@@ -253,6 +256,28 @@ class Context:
     def assemble_frames_device(self, d_cols_u8_ptr, n_loc, block_stride, n_frames, frame_stride, d_imgs_ptr, stream=None):
         self._ck(self._L.rr_assemble_frames_device(self._h, d_cols_u8_ptr, int(n_loc), int(block_stride), int(n_frames),
                                                    int(frame_stride), d_imgs_ptr, stream))
+
+    @staticmethod
+    def _material_sets(sets):
+        a = np.ascontiguousarray(np.asarray(sets, dtype=np.float32))
+        if a.ndim != 3 or a.shape[2] != 4:
+            raise ValueError("material sets must have shape [n_sets][n_materials][4] (velocity, ambient, diffuse, specular)")
+        return a
+
+    def simulate_material_sets_device(self, pose, sets, d_imgs_ptr, stream=None):
+        """n_sets material tables, one pose -> images [n_sets][n_cells][n_angles] in HBM."""
+        a = self._material_sets(sets)
+        p = np.ascontiguousarray(pose, dtype=np.float32)
+        self._ck(self._L.rr_simulate_material_sets_device(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], d_imgs_ptr, stream))
+
+    def simulate_material_sets(self, pose, sets):
+        """Host-buffer variant: returns a uint8 array [n_sets][n_cells][n_angles]."""
+        a = self._material_sets(sets)
+        p = np.ascontiguousarray(pose, dtype=np.float32)
+        n_cells = self.cfg.n_cells if self.cfg is not None else 1
+        out = np.zeros((a.shape[0], n_cells, self.n_angles), dtype=np.uint8)
+        self._ck(self._L.rr_simulate_material_sets(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
 
     def simulate_device(self, pose, d_img_ptr, stream=None):
         p = np.ascontiguousarray(pose, np.float32)

@@ -140,6 +140,22 @@ class RadarHIP:
         self.last_stats = stats
         return msg
 
+    def simulateMaterialSets(self, sets, stamp=0.0):
+        """The gen_radar_image action of the optimisation loop (action/GenRadarImage.action,
+        scripts/radaray_opti.py:170-200), batched: `sets` is a list of material lists (each as long
+        as loadParams() gave); returns one mono8 Image per set for the current pose, one call."""
+        if not self.updateTsm():
+            print("Couldn't get Transform between sensor and map. Skipping...")
+            return []
+        self._push()
+        n_mat = len(self.m_params.materials)
+        if any(len(x) != n_mat for x in sets):
+            raise ValueError("every material set needs %d entries" % n_mat)
+        arr = [[m.astuple() for m in x] for x in sets]
+        imgs = self._ctx.simulate_material_sets(self.Tsm_last, arr)
+        return [Image(header=Header(stamp=stamp, frame_id=self.m_sensor_frame), height=u8.shape[0], width=u8.shape[1],
+                      encoding="mono8", step=u8.shape[1], data=u8) for u8 in imgs]
+
     @property
     def context(self):
         return self._ctx

@@ -47,6 +47,13 @@ int main(int argc, char** argv)
         uint32_t hw[2] = { img->height, img->width };
         o.write((const char*)hw, 8);
         o.write((const char*)img->data.data(), (std::streamsize)img->data.size());
+        // parameter batch: table 0 = the loaded materials (must reproduce img), table 1 = ambient halved
+        std::vector<std::vector<RadarMaterial>> sets(2, m);
+        for (auto& x : sets[1]) x.ambient *= 0.5f;
+        std::vector<ImagePtr> batch = radar.simulateMaterialSets(sets, 43.0);
+        if (batch.size() != 2 || batch[0]->data != img->data || batch[1]->data == img->data) {
+            std::fprintf(stderr, "simulateMaterialSets mismatch: %s\n", radar.lastError().c_str()); return 7;
+        }
         const rr_stats& st = radar.lastStats();
         std::printf("ok %u x %u wave_passes %llu signals %llu\n", img->height, img->width,
                     (unsigned long long)st.wave_passes, (unsigned long long)st.signals);

@@ -259,6 +259,13 @@ def test_radar_interface_mirror(native_lib, oracle):
                                 r.m_cfg, r.m_waves_start, r.Tsm_last)
     d = image_diff(r.last_f32, of, msg.data, o8)
     assert d["mean_dev"] <= MEAN_DEV_TOL and d["u8_max"] <= 1
+    # the batched gen_radar_image action: set 0 = current materials reproduces simulate()
+    import copy
+    alt = copy.deepcopy(r.m_params.materials)
+    alt[1].ambient *= 0.5
+    imgs = r.simulateMaterialSets([r.m_params.materials, alt], 13.0)
+    assert len(imgs) == 2 and np.array_equal(imgs[0].data, msg.data) and not np.array_equal(imgs[1].data, msg.data)
+    assert imgs[1].header.stamp == 13.0 and imgs[1].encoding == "mono8"
 
 
 def test_sharded_slot_path_on_one_rank(native_lib):
@@ -466,3 +473,48 @@ def test_assemble_matches_numpy(native_lib, n_cells):
             torch.cuda.synchronize()
             assert np.array_equal(d_one.cpu().numpy(), got[0])
         c.close()
+
+
+def test_material_sets_batch_equals_one_by_one(native_lib, oracle):
+    """Parameter batch (the objective evaluations of scripts/radaray_opti.py): K
+    material tables, one pose, one call.  Image k must be bit-identical to rr_set_materials(set k)
+    + rr_simulate, and set 0 is checked against the oracle."""
+    import torch
+    s = gen.two_room_scene()
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=2)
+    rnd = (np.random.RandomState(3).uniform(0, 1, 400) * 1000.0).astype(np.float32)
+    base_mats = params.kaist_materials() + [params.PENETRABLE]
+    base = np.asarray([m.astuple() for m in base_mats], np.float32)
+    rs = np.random.RandomState(11)
+    K = 6
+    sets = np.repeat(base[None], K, axis=0)
+    for k in range(1, K):      # the optimiser's bounds (radaray_opti.py:60-67); air (id 0) stays
+        sets[k, 1:, 0] = rs.uniform(0.0, 0.3, sets.shape[1] - 1)
+        sets[k, 1:, 1] = rs.uniform(0.0, 1.0, sets.shape[1] - 1)
+        sets[k, 1:, 2] = rs.uniform(0.0, 1.0, sets.shape[1] - 1)
+        sets[k, 1:, 3] = rs.uniform(0.0, 5000.0, sets.shape[1] - 1)
+    sets[K - 1, 1, 0] = 0.0    # a velocity-0 material (total reflection branch, SURVEY App. A 3)
+    b = golden_beams(40)
+    pose = scenes.default_pose("box12")
+    c = _ctx(native_lib, s, cfg, base_mats, b, noise=rnd)
+    got = c.simulate_material_sets(pose, sets)
+    d_imgs = torch.zeros((K, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    c.simulate_material_sets_device(pose, sets, d_imgs.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    c.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_imgs.cpu().numpy(), got)
+    assert len({got[k].tobytes() for k in range(K)}) == K          # the sets really differ
+    from radarays_ros_amd.params import RadarMaterial
+    for k in range(K):
+        mats_k = [RadarMaterial(*[float(x) for x in sets[k, i]]) for i in range(sets.shape[1])]
+        c.set_materials(mats_k, s["object_materials"], 0)
+        one, _, _ = c.simulate(pose)
+        assert np.array_equal(one, got[k]), k
+    c.close()
+    # one of the random sets against the oracle
+    mats1 = [RadarMaterial(*[float(x) for x in sets[1, i]]) for i in range(sets.shape[1])]
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"])
+    o8, _, _ = oracle.simulate(sc, mats_tuple(mats1), s["object_materials"], cfg, b, pose, noise_rnd=rnd)
+    diff = np.abs(o8.astype(np.int16) - got[1].astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() <= U8_MISMATCH_TOL
