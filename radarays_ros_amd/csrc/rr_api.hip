@@ -806,6 +806,10 @@ int rr_get_stats(rr_ctx* c, rr_stats* st)
     RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
     st->nodes_visited = h.nodes; st->tris_tested = h.tris; st->overflow = h.overflow;
     if (getenv("RR_TRACE_STATS")) fprintf(stderr, "[rr stats] waves %u wave_iters %llu (avg %.1f) max_iters %u\n", h.n_waves, h.wave_iters, h.n_waves ? (double)h.wave_iters / h.n_waves : 0.0, h.max_iters);
+    if (getenv("RR_TRACE_STATS") && h.n_waves)
+        fprintf(stderr, "[rr stats] per wave: iterations %.2f, issuing node path %.2f, leaf path %.2f, live quad-steps %.1f (of 16 x iterations = %.1f)\n",
+                (double)h.it_all / h.n_waves, (double)h.it_node / h.n_waves, (double)h.it_leaf / h.n_waves,
+                (double)h.quad_steps / h.n_waves, 16.0 * h.it_all / h.n_waves);
     const size_t n = (size_t)L.last_n_seg * (size_t)L.last_n_passes;
     if (n && L.d_seg_stats.p) {
         std::vector<SegStats> ss(n);

@@ -69,6 +69,7 @@ struct Counters {
     unsigned long long wave_iters;    // sum over waves of traversal-loop iterations
     unsigned int max_iters, n_waves;  // longest wave, wave count
     unsigned int overflow, pad;       // error bits, set on rare error paths
+    unsigned long long it_all, it_node, it_leaf, quad_steps;   // stats mode: wave-loop iterations (all / issuing the node path / the leaf path), quad steps
 };
 
 // per (pass, azimuth) counters, written once by the kernel that finishes the pass

@@ -90,7 +90,7 @@ template <bool STATS, bool SPILL>
 __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris,
                                const RaySetup& R, float range_max,
                                uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gray,
-                               unsigned& n_nodes, unsigned& n_tris)
+                               unsigned& n_nodes, unsigned& n_tris, unsigned* wstat = nullptr)
 {
     const int q = threadIdx.x & 3;
     const int wave = threadIdx.x >> 6;
@@ -113,6 +113,10 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     while (true) {
         // ---- ONE batch of loads per step, whatever the step is (single s_waitcnt) ----
         const bool leaf = (cur & kLeafFlag) != 0;
+        if (STATS && wstat) {   // wave-level shape of this iteration (same value in every live lane)
+            wstat[0]++; wstat[1] += __ballot(!leaf) != 0ull; wstat[2] += __ballot(leaf) != 0ull;
+            wstat[3] += (unsigned)__builtin_popcountll(__ballot(true)) >> 2;
+        }
         const uint32_t first = cur & 0x0FFFFFFFu;
         const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
         const float4* p = leaf ? (tri4 + 3 * (size_t)(first + q)) : (node4 + 8 * (size_t)cur + 2 * q);
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     const bool active = j >= 0;
 
     unsigned nn = 0, nt = 0;
+    unsigned ws[4] = { 0, 0, 0, 0 };
     if (active) {
         RaySetup R;
         R.o = { s_ray[0][r], s_ray[1][r], s_ray[2][r] }; R.d = { s_ray[3][r], s_ray[4][r], s_ray[5][r] };
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         R.oox = s_ray[9][r]; R.ooy = s_ray[10][r]; R.ooz = s_ray[11][r];
         const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
         const Hit h = traverse<STATS, SPILL>(P.nodes, P.tris, R, P.range_max, lds_stack, P.stack_lds,
-                                       P.spill, P.spill_stride, gray, nn, nt);
+                                       P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
             P.hit_t[hk] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
@@ -275,6 +280,18 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
             atomicAdd(&P.counters->wave_iters, (unsigned long long)it);
             atomicMax(&P.counters->max_iters, it);
             atomicAdd(&P.counters->n_waves, 1u);
+        }
+        // the lane that stayed longest in the loop saw every iteration of the wave
+        unsigned a = ws[0], b = ws[1], c2 = ws[2], d2 = ws[3];
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned a2 = __shfl_down(a, off), b2 = __shfl_down(b, off), c3 = __shfl_down(c2, off), d3 = __shfl_down(d2, off);
+            if (a2 > a) { a = a2; b = b2; c2 = c3; d2 = d3; }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&P.counters->it_all, (unsigned long long)a);
+            atomicAdd(&P.counters->it_node, (unsigned long long)b);
+            atomicAdd(&P.counters->it_leaf, (unsigned long long)c2);
+            atomicAdd(&P.counters->quad_steps, (unsigned long long)d2);
         }
     }
 }
