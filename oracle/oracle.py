@@ -69,7 +69,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(_HERE, "libradarays_oracle.so")
+    so = os.environ.get("RADARAYS_ORACLE_LIB") or os.path.join(_HERE, "libradarays_oracle.so")   # override: `make asan`
     if not os.path.exists(so):
         build()
     L = C.CDLL(so)
