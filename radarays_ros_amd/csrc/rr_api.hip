@@ -110,7 +110,10 @@ struct rr_ctx {
     DevBuf<int32_t> d_objmat;
     DevBuf<float> d_smear, d_noise, d_motion, d_decay;
     DevBuf<uint8_t> d_param_imgs;   // rr_simulate_material_sets: images before the D2H copy
-    bool tables_dirty = true;
+    // what upload_tables() has to refresh (the reference node re-reads its parameters before EVERY
+    // frame, radar_simulator.cpp:85,200: setters that bring nothing new must cost nothing)
+    enum : unsigned { D_CFG = 1, D_BEAMS = 2, D_MAT = 4, D_NOISE = 8, D_MOTION = 16, D_ALL = 31 };
+    unsigned tables_dirty = D_ALL;
 
     // frame lanes: each owns a full set of frame buffers + a stream, so consecutive
     // frames overlap on the GPU (the tail of one frame's k_trace runs beside the next frame)
@@ -196,6 +199,8 @@ int upload_tables(rr_ctx* c)
     if (!c->tables_dirty) return 0;
     RR_HIP(c, hipDeviceSynchronize());   // frames in flight on the lanes still read the old tables
     const rr_config& g = c->cfg;
+    const unsigned dirty = c->tables_dirty;
+    if (dirty & rr_ctx::D_CFG) {
     // Tas.R = EulerAngles{0,0,theta(angle)} -> quaternion (rmagine ZYX), RadarCPU.cpp:202
     std::vector<float4> qas((size_t)g.n_angles);
     for (int k = 0; k < g.n_angles; k++) {
@@ -213,7 +218,9 @@ int upload_tables(rr_ctx* c)
     }
     RR_HIP(c, c->d_qas.ensure(qas.size()));
     RR_HIP(c, hipMemcpy(c->d_qas.p, qas.data(), qas.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
 
+    if (dirty & rr_ctx::D_BEAMS) {
     const size_t nb = c->beams.size() / 3;
     std::vector<float4> b4(nb);
     for (size_t i = 0; i < nb; i++) b4[i] = make_float4(c->beams[3 * i], c->beams[3 * i + 1], c->beams[3 * i + 2], 0.0f);
@@ -247,7 +254,9 @@ int upload_tables(rr_ctx* c)
         RR_HIP(c, c->d_beam_order.ensure(nb));
         if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order.p, order.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    }
 
+    if (dirty & rr_ctx::D_MAT) {
     std::vector<float4> m4(c->materials.size());
     for (size_t i = 0; i < m4.size(); i++)
         m4[i] = make_float4(c->materials[i].velocity, c->materials[i].ambient, c->materials[i].diffuse, c->materials[i].specular);
@@ -256,7 +265,9 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, c->d_objmat.ensure(c->object_materials.size()));
     if (!c->object_materials.empty())
         RR_HIP(c, hipMemcpy(c->d_objmat.p, c->object_materials.data(), c->object_materials.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
 
+    if (dirty & rr_ctx::D_CFG) {
     make_smear(g, c->smear, c->smear_mode);
     RR_HIP(c, c->d_smear.ensure(c->smear.size()));
     if (!c->smear.empty()) RR_HIP(c, hipMemcpy(c->d_smear.p, c->smear.data(), c->smear.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -265,17 +276,20 @@ int upload_tables(rr_ctx* c)
     launch_decay_table(c->d_decay.p, g.n_cells, g.resolution, g.ambient_noise_energy_loss, nullptr);
     RR_HIP(c, hipGetLastError());
     RR_HIP(c, hipDeviceSynchronize());
+    }
 
+    if (dirty & (rr_ctx::D_NOISE | rr_ctx::D_CFG)) {
     std::vector<float> nz((size_t)g.n_angles, 0.0f);
     for (size_t i = 0; i < nz.size() && i < c->noise.size(); i++) nz[i] = c->noise[i];
     RR_HIP(c, c->d_noise.ensure(nz.size()));
     RR_HIP(c, hipMemcpy(c->d_noise.p, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (!c->motion.empty()) {
+    }
+    if ((dirty & (rr_ctx::D_MOTION | rr_ctx::D_CFG)) && !c->motion.empty()) {
         if (c->motion.size() != 7 * (size_t)g.n_angles) return fail(c, -3, "rr_set_motion_poses: need n_angles poses");
         RR_HIP(c, c->d_motion.ensure(c->motion.size()));
         RR_HIP(c, hipMemcpy(c->d_motion.p, c->motion.data(), c->motion.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    c->tables_dirty = false;
+    c->tables_dirty = 0;
     return 0;
 }
 
@@ -563,10 +577,15 @@ int rr_set_materials(rr_ctx* c, const rr_material* materials, size_t n_materials
     for (size_t i = 0; i < n_objects; i++)
         if (object_materials[i] < 0 || (size_t)object_materials[i] >= n_materials)
             return fail(c, -3, "rr_set_materials: object_materials entry out of range");
+    if (c->have_materials && c->materials.size() == n_materials && c->object_materials.size() == n_objects &&
+        c->material_id_air == material_id_air &&
+        std::memcmp(c->materials.data(), materials, n_materials * sizeof(rr_material)) == 0 &&
+        (n_objects == 0 || std::memcmp(c->object_materials.data(), object_materials, n_objects * sizeof(int32_t)) == 0))
+        return 0;   // the per-frame loadParams() of the reference node, nothing new
     c->materials.assign(materials, materials + n_materials);
     c->object_materials.assign(object_materials, object_materials + n_objects);
     c->material_id_air = material_id_air;
-    c->have_materials = true; c->tables_dirty = true;
+    c->have_materials = true; c->tables_dirty |= rr_ctx::D_MAT;
     return 0;
 }
 
@@ -584,8 +603,9 @@ int rr_set_config(rr_ctx* c, const rr_config* cfg)
     if (w < 0 || w > 256) return fail(c, -3, "rr_set_config: smear width must be in [0, 256]");
     if (cfg->ambient_noise < 0 || cfg->ambient_noise > 2) return fail(c, -3, "rr_set_config: ambient_noise must be 0..2");
     if (!(cfg->resolution > 0.0)) return fail(c, -3, "rr_set_config: resolution must be > 0");
+    if (c->have_cfg && std::memcmp(&c->cfg, cfg, sizeof(rr_config)) == 0) return 0;
     c->cfg = *cfg;
-    c->have_cfg = true; c->tables_dirty = true;
+    c->have_cfg = true; c->tables_dirty |= rr_ctx::D_CFG;
     return 0;
 }
 
@@ -595,8 +615,9 @@ int rr_set_beam_samples(rr_ctx* c, const float* dirs, size_t n)
     if (n && !dirs) return fail(c, -3, "rr_set_beam_samples: null dirs");
     if (n > 65536) return fail(c, -3, "rr_set_beam_samples: more than 65536 samples");
     for (size_t i = 0; i < 3 * n; i++) if (!std::isfinite(dirs[i])) return fail(c, -3, "rr_set_beam_samples: non-finite direction");
+    if (c->beams.size() == 3 * n && (n == 0 || std::memcmp(c->beams.data(), dirs, 3 * n * sizeof(float)) == 0)) return 0;
     c->beams.assign(dirs, dirs + 3 * n);
-    c->tables_dirty = true;
+    c->tables_dirty |= rr_ctx::D_BEAMS;
     return 0;
 }
 
@@ -605,7 +626,7 @@ int rr_set_noise_offsets(rr_ctx* c, const float* rnd, size_t n)
     if (!c) return -1;
     if (n && !rnd) return fail(c, -3, "rr_set_noise_offsets: null pointer");
     c->noise.assign(rnd, rnd + n);
-    c->tables_dirty = true;
+    c->tables_dirty |= rr_ctx::D_NOISE;
     return 0;
 }
 
@@ -615,7 +636,7 @@ int rr_set_motion_poses(rr_ctx* c, const float* poses, size_t n)
     if (n && !poses) return fail(c, -3, "rr_set_motion_poses: null pointer");
     for (size_t i = 0; i < 7 * n; i++) if (!std::isfinite(poses[i])) return fail(c, -3, "rr_set_motion_poses: non-finite pose");
     c->motion.assign(poses, poses + 7 * n);
-    c->tables_dirty = true;
+    c->tables_dirty |= rr_ctx::D_MOTION;
     return 0;
 }
 

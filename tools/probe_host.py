@@ -15,3 +15,16 @@ for k in range(K): c.simulate(poses[k % 16])
 dt = time.time() - t0
 print("rr_simulate (host buffers, synchronous, D2H + host transpose): %.1f images/s, %.3f ms/frame" % (K / dt, 1e3 * dt / K))
 c.close()
+# the reference node's loop (radar_simulator.cpp:83-96): loadParams() + fresh noise offsets before EVERY frame
+c = native.Context(0)
+c.set_mesh(s["verts"], s["faces"], s["face_object_id"]); mats = materials_for(s)
+c.set_config(cfg); c.set_beam_samples(golden_beams(200))
+rs = np.random.RandomState(1)
+for k in range(K + 5):
+    if k == 5: t0 = time.time()
+    c.set_materials(mats, s["object_materials"], 0); c.set_config(cfg)
+    c.set_noise_offsets((rs.uniform(0, 1, 400) * 1000).astype(np.float32))
+    c.simulate(poses[k % 16])
+dt = time.time() - t0
+print("node loop (loadParams + config + new noise offsets + rr_simulate per frame): %.1f images/s, %.3f ms/frame" % (K / dt, 1e3 * dt / K))
+c.close()
