@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 {
     extern __shared__ float lds_col[];              // [n_cells] slice
     __shared__ SigRec s_sig[kSigChunk];
-    __shared__ float s_w[256];
+    __shared__ double s_w[256];                     // smear weights, widened once (the replay multiplies in f64)
     __shared__ unsigned long long s_tiles[2];
     __shared__ float s_red[kColWaves];
     __shared__ unsigned char s_perm[256];
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     const size_t base2 = (size_t)seg * 2 * P.cap;
 
     for (int i = tid; i < n_cells; i += kColThreads) lds_col[i] = 0.0f;
-    if (tid < W && P.signal_denoising > 0) s_w[tid] = P.smear[tid];
+    if (tid < W && P.signal_denoising > 0) s_w[tid] = (double)P.smear[tid];
     if (tid < 256) { s_perm[tid] = c_perm[tid]; s_grad[tid] = p_grad_coef(c_perm[tid]); }
     __syncthreads();
 
@@ -752,7 +752,17 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
             const int tlo = t * 64, thi = tlo + 63;
             const bool g_ok = g > 0 && g < n_cells;      // RadarCPU.cpp:424 (bin 0 is never written)
             float acc = (g < n_cells) ? lds_col[g] : 0.0f;
-            // scan 64 signals per step; replay the overlapping ones in order
+            // scan 64 signals per step; replay the overlapping ones in order.  A lane outside 0 < g < C
+            // gets a bin index that fails every `vid < W` test (RadarCPU.cpp:424: bin 0 is never written)
+            const int gb = g_ok ? g : -0x40000000;
+            const unsigned Wu = (unsigned)W;
+            // one replay: acc = (float)((double)acc + (double)strength * w[g - first])   (RadarCPU.cpp:426)
+#define RR_REPLAY(F, S, WV)                                                                   \
+            {                                                                                 \
+                const float nv = (float)((double)acc + (double)(S) * (WV));                   \
+                acc = ((unsigned)(gb - (F)) < Wu) ? nv : acc;                                 \
+            }
+#define RR_WLOAD(F) s_w[min((unsigned)(gb - (F)), Wu - 1u)]
             for (int b0 = 0; b0 < n; b0 += 64) {
                 const int i = b0 + lane;
                 SigRec r; r.cell = 0x40000000; r.strength = 0.0f;
@@ -760,20 +770,41 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 const int first = r.cell - mode;
                 const bool ov = !(first > thi || first + W - 1 < tlo);
                 unsigned long long m = __ballot(ov);
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int f_b = __builtin_amdgcn_readlane(first, b);
-                    const float s_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), b));
-                    const int vid = g - f_b;
-                    if (P.signal_denoising > 0) {
-                        if (vid >= 0 && vid < W && g_ok)
-                            acc = (float)((double)acc + (double)s_b * (double)s_w[vid]);   // :426
-                    } else {
-                        if (vid == 0 && g < n_cells) acc = fmaxf(acc, s_b);               // :439
+                if (P.signal_denoising > 0) {
+                    // dense clusters (a wall: many echoes in the same bins): four replays per step, their
+                    // weight reads issued together, the f64-add / f32-round chain kept in signal order
+                    while (__builtin_popcountll(m) >= 4) {
+                        const int l0 = __builtin_ctzll(m); m &= m - 1;
+                        const int l1 = __builtin_ctzll(m); m &= m - 1;
+                        const int l2 = __builtin_ctzll(m); m &= m - 1;
+                        const int l3 = __builtin_ctzll(m); m &= m - 1;
+                        const int f0 = __builtin_amdgcn_readlane(first, l0), f1 = __builtin_amdgcn_readlane(first, l1);
+                        const int f2 = __builtin_amdgcn_readlane(first, l2), f3 = __builtin_amdgcn_readlane(first, l3);
+                        const float s0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l0));
+                        const float s1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l1));
+                        const float s2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l2));
+                        const float s3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l3));
+                        const double w0 = RR_WLOAD(f0), w1 = RR_WLOAD(f1), w2 = RR_WLOAD(f2), w3 = RR_WLOAD(f3);
+                        RR_REPLAY(f0, s0, w0) RR_REPLAY(f1, s1, w1) RR_REPLAY(f2, s2, w2) RR_REPLAY(f3, s3, w3)
+                    }
+                    while (m) {
+                        const int b = __builtin_ctzll(m); m &= m - 1;
+                        const int f_b = __builtin_amdgcn_readlane(first, b);
+                        const float s_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), b));
+                        const double w_b = RR_WLOAD(f_b);
+                        RR_REPLAY(f_b, s_b, w_b)
+                    }
+                } else {
+                    while (m) {
+                        const int b = __builtin_ctzll(m); m &= m - 1;
+                        const int f_b = __builtin_amdgcn_readlane(first, b);
+                        const float s_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), b));
+                        if (g - f_b == 0 && g < n_cells) acc = fmaxf(acc, s_b);               // :439
                     }
                 }
             }
+#undef RR_REPLAY
+#undef RR_WLOAD
             if (g < n_cells) lds_col[g] = acc;
         }
         __syncthreads();
