@@ -518,3 +518,29 @@ def test_material_sets_batch_equals_one_by_one(native_lib, oracle):
     o8, _, _ = oracle.simulate(sc, mats_tuple(mats1), s["object_materials"], cfg, b, pose, noise_rnd=rnd)
     diff = np.abs(o8.astype(np.int16) - got[1].astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).mean() <= U8_MISMATCH_TOL
+
+
+@pytest.mark.parametrize("n_angles,scroll", [(90, 8), (101, 7), (1, 0)])
+def test_other_azimuth_counts(native_lib, oracle, n_angles, scroll):
+    """The reference fixes 400 azimuths (Radar.cpp:27-29); the ABI takes n_angles / theta_inc.  90 takes the
+    four-azimuth assemble path, 101 (odd) the byte path, 1 is the degenerate sweep."""
+    s = gen.two_room_scene()
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=2, scroll_image=scroll)
+    rnd = (np.random.RandomState(5).uniform(0, 1, n_angles) * 1000.0).astype(np.float32)
+    b = golden_beams(32)
+    pose = scenes.default_pose("box12")
+    c = native_lib.Context(0)
+    c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    c.set_materials(mats, s["object_materials"], 0)
+    c.set_config(cfg, n_angles)
+    c.set_beam_samples(b)
+    c.set_noise_offsets(rnd)
+    g8, gf, gst = c.simulate(pose, 0, n_angles, want_f32=True)
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
+    o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, b, pose, noise_rnd=rnd,
+                                  n_angles=n_angles)
+    assert g8.shape == (cfg.n_cells, n_angles) and gst["wave_passes"] == ost["wave_passes"]
+    d = image_diff(gf, of, g8, o8)
+    assert d["mean_dev"] <= MEAN_DEV_TOL and d["u8_max"] <= 1 and d["u8_mismatch_frac"] <= U8_MISMATCH_TOL, d
+    c.close()
