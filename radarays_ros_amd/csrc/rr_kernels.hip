@@ -700,6 +700,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     __shared__ float s_red[kColWaves];
     __shared__ unsigned char s_perm[256];
     __shared__ double2 s_grad[256];
+    __shared__ int2 s_list[kColWaves][64];         // per wave: overlapping signals of one 64-signal batch
 
     const int seg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -753,16 +754,19 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
             const bool g_ok = g > 0 && g < n_cells;      // RadarCPU.cpp:424 (bin 0 is never written)
             float acc = (g < n_cells) ? lds_col[g] : 0.0f;
             // scan 64 signals per step; replay the overlapping ones in order.  A lane outside 0 < g < C
-            // gets a bin index that fails every `vid < W` test (RadarCPU.cpp:424: bin 0 is never written)
-            const int gb = g_ok ? g : -0x40000000;
-            const unsigned Wu = (unsigned)W;
+            // gets a bin index that fails every range test (RadarCPU.cpp:424: bin 0 is never written)
+            const int gb8 = g_ok ? 8 * g : -0x40000000;      // byte offset of bin g in the f64 weight table
+            const unsigned W8 = 8u * (unsigned)W;
+            const char* wbytes = reinterpret_cast<const char*>(s_w);
+            int2* list = s_list[wid];
             // one replay: acc = (float)((double)acc + (double)strength * w[g - first])   (RadarCPU.cpp:426)
-#define RR_REPLAY(F, S, WV)                                                                   \
-            {                                                                                 \
-                const float nv = (float)((double)acc + (double)(S) * (WV));                   \
-                acc = ((unsigned)(gb - (F)) < Wu) ? nv : acc;                                 \
+#define RR_REPLAY(E)                                                                                     \
+            {                                                                                            \
+                const unsigned off = (unsigned)(gb8 - (E).x);                                            \
+                const double wv = *reinterpret_cast<const double*>(wbytes + min(off, W8 - 8u));          \
+                const float nv = (float)((double)acc + (double)__int_as_float((E).y) * wv);              \
+                acc = (off < W8) ? nv : acc;                                                             \
             }
-#define RR_WLOAD(F) s_w[min((unsigned)(gb - (F)), Wu - 1u)]
             for (int b0 = 0; b0 < n; b0 += 64) {
                 const int i = b0 + lane;
                 SigRec r; r.cell = 0x40000000; r.strength = 0.0f;
@@ -770,30 +774,25 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 const int first = r.cell - mode;
                 const bool ov = !(first > thi || first + W - 1 < tlo);
                 unsigned long long m = __ballot(ov);
+                if (m == 0ull) continue;
                 if (P.signal_denoising > 0) {
-                    // dense clusters (a wall: many echoes in the same bins): four replays per step, their
-                    // weight reads issued together, the f64-add / f32-round chain kept in signal order
-                    while (__builtin_popcountll(m) >= 4) {
-                        const int l0 = __builtin_ctzll(m); m &= m - 1;
-                        const int l1 = __builtin_ctzll(m); m &= m - 1;
-                        const int l2 = __builtin_ctzll(m); m &= m - 1;
-                        const int l3 = __builtin_ctzll(m); m &= m - 1;
-                        const int f0 = __builtin_amdgcn_readlane(first, l0), f1 = __builtin_amdgcn_readlane(first, l1);
-                        const int f2 = __builtin_amdgcn_readlane(first, l2), f3 = __builtin_amdgcn_readlane(first, l3);
-                        const float s0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l0));
-                        const float s1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l1));
-                        const float s2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l2));
-                        const float s3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), l3));
-                        const double w0 = RR_WLOAD(f0), w1 = RR_WLOAD(f1), w2 = RR_WLOAD(f2), w3 = RR_WLOAD(f3);
-                        RR_REPLAY(f0, s0, w0) RR_REPLAY(f1, s1, w1) RR_REPLAY(f2, s2, w2) RR_REPLAY(f3, s3, w3)
+                    // the overlapping signals of this batch, compacted in order into a wave-private list:
+                    // the replay then reads them back with uniform (broadcast) LDS reads -- no lane
+                    // extraction -- and the reads of several replays are in flight together; the
+                    // f64-add / f32-round chain itself stays in signal order
+                    const int cnt = __builtin_popcountll(m);
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (ov) list[pos] = make_int2(8 * first, __float_as_int(r.strength));
+                    // same wave, in-order LDS: make the writes of the other lanes visible to the reads below
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    int k = 0;
+                    for (; k + 4 <= cnt; k += 4) {
+                        const int2 e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
+                        RR_REPLAY(e0) RR_REPLAY(e1) RR_REPLAY(e2) RR_REPLAY(e3)
                     }
-                    while (m) {
-                        const int b = __builtin_ctzll(m); m &= m - 1;
-                        const int f_b = __builtin_amdgcn_readlane(first, b);
-                        const float s_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), b));
-                        const double w_b = RR_WLOAD(f_b);
-                        RR_REPLAY(f_b, s_b, w_b)
-                    }
+                    for (; k < cnt; k++) { const int2 e = list[k]; RR_REPLAY(e) }
                 } else {
                     while (m) {
                         const int b = __builtin_ctzll(m); m &= m - 1;
@@ -804,7 +803,6 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 }
             }
 #undef RR_REPLAY
-#undef RR_WLOAD
             if (g < n_cells) lds_col[g] = acc;
         }
         __syncthreads();
