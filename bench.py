@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--ambient-noise", type=int, default=2)
     ap.add_argument("--strong", action="store_true", help="N>1: one frame per step + all-gather")
     ap.add_argument("--force-slots", action="store_true", help="run the N>1 step loop (with its collective) on one rank (debug)")
+    ap.add_argument("--slots", type=int, default=4, help="steps in flight (streams + buffer sets); RR_LANES must be >= slots")
     ap.add_argument("--frames-per-rank", type=int, default=4,
                     help="frames each GPU finishes per step (one set of launches); a step = N x this many frames")
     args = ap.parse_args()
@@ -113,7 +114,7 @@ def main():
 
     shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank),
                          force_collective=args.force_slots, strong=args.strong,
-                         frames_per_rank=args.frames_per_rank)
+                         frames_per_rank=args.frames_per_rank, n_slots=args.slots)
     fps = shard.frames_per_step
     stream = torch.cuda.current_stream()
 
@@ -144,6 +145,14 @@ def main():
     t1 = time.perf_counter()
     trace_ms, trace_launches = ctx.kernel_time("trace", reset=True)
     ctx.set_timing_mode(0)
+    # k_trace alone on the GPU (one step at a time, nothing else in flight): the kernel's own speed, as
+    # opposed to its duration while 4 steps share the chip in the timed region above
+    ctx.set_timing_mode(2)
+    for k in range(12):
+        step(k)
+        torch.cuda.synchronize()
+    iso_ms, iso_launches = ctx.kernel_time("trace", reset=True)
+    ctx.set_timing_mode(0)
     # one instrumented step outside the timed region: measured node / triangle fetches per wave-pass
     ctx.set_stats_mode(True)
     step(0)
@@ -170,6 +179,7 @@ def main():
         avg_trace_s = (trace_ms / max(trace_launches, 1)) * 1e-3
         bytes_per_launch = wave_passes_frame_rank / launches_per_frame * b_wp      # one step of this rank
         achieved = bytes_per_launch / avg_trace_s / 1e9 if avg_trace_s > 0 else 0.0
+        iso_us = 1e3 * iso_ms / max(iso_launches, 1)
         wp2 = max(int(st2["wave_passes"]), 1)
         measured_b_wp = (st2["nodes_visited"] * 128 + st2["tris_tested"] * 48) / wp2 + 132
         traffic = None
@@ -203,7 +213,11 @@ def main():
                          # SURVEY §8d "reported figure": measured visits of THIS BVH4 (128-B nodes, 48-B triangles)
                          "measured_bytes_per_wave_pass": round(measured_b_wp, 1),
                          "achieved_measured": round(achieved * measured_b_wp / b_wp, 2),
-                         "avg_launch_us": round(avg_trace_s * 1e6, 2), "launches": int(trace_launches)},
+                         "avg_launch_us": round(avg_trace_s * 1e6, 2), "launches": int(trace_launches),
+                         "steps_in_flight": int(args.slots),
+                         "isolated": {"avg_launch_us": round(iso_us, 2),
+                                      "achieved": round(bytes_per_launch / (iso_us * 1e-6) / 1e9, 2) if iso_us > 0 else None,
+                                      "frac": round(bytes_per_launch / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if iso_us > 0 else None}},
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -119,6 +119,8 @@ struct rr_ctx {
     // frames overlap on the GPU (the tail of one frame's k_trace runs beside the next frame)
     std::vector<Lane> lanes;
     size_t next_lane = 0, last_lane = 0;
+    size_t next_stream_lane = 0;
+    int stream_lanes = 3;          // lanes whose own stream rr_simulate_device uses
 
     bool stats_mode = false;
     int timing = 0;   // 0 off, 1 every kernel, 2 k_trace only
@@ -489,8 +491,13 @@ rr_ctx* rr_create(int device)
         g_create_error = "rr_create: hipStreamCreate failed"; delete c; return nullptr;
     }
     rr_default_config(&c->cfg);
-    int n_lanes = getenv("RR_LANES") ? atoi(getenv("RR_LANES")) : 3;
+    // 4 buffer sets: the sharded step loop (dist.py) keeps 4 steps in flight on its own streams
+    // (measured optimum: 4 streams = 4 hardware queues); rr_simulate_device, whose frames run on the
+    // lanes' OWN streams beside the caller's stream, rotates over the first 3 only (same reason)
+    int n_lanes = getenv("RR_LANES") ? atoi(getenv("RR_LANES")) : 4;
     n_lanes = std::max(1, std::min(n_lanes, 8));
+    c->stream_lanes = getenv("RR_STREAM_LANES") ? std::max(1, std::min(atoi(getenv("RR_STREAM_LANES")), n_lanes))
+                                                : std::min(3, n_lanes);
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -792,7 +799,7 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
     // (no dependency on the caller's stream), only the assemble -- the one kernel that touches
     // the caller's buffer -- is ordered on the caller's stream.  The lane is reused only after
     // that assemble has consumed its columns.
-    const size_t li = c->next_lane++ % c->lanes.size();
+    const size_t li = c->next_stream_lane++ % (size_t)c->stream_lanes;
     Lane& L = c->lanes[li];
     c->last_lane = li;
     if (L.buf_seg < A) { rc = ensure_frame_buffers(c, L, A, false); if (rc) return rc; }

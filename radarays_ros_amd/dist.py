@@ -75,7 +75,7 @@ class AzimuthShard:
                 with frames r*fpr .. r*fpr+fpr-1); strong mode renders one frame per step
                 (every rank ends up with it)."""
 
-    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=3, strong=False,
+    def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=4, strong=False,
                  frames_per_rank=1, force_collective=False):
         self.ctx, self.n_cells, self.n_angles = ctx, n_cells, n_angles
         self.rank, self.world, self.device = rank, world, device
