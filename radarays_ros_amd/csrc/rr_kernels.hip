@@ -54,7 +54,7 @@ struct Hit { float t; uint32_t tri; uint32_t face; };
 // quad) and spills to global memory beyond `stack_lds` entries.
 // ---------------------------------------------------------------------------
 constexpr int kRaysPerWave = 16;
-constexpr int kTraceThreads = 256;                       // 64 rays per workgroup
+constexpr int kTraceThreads = 128;                       // 32 rays per workgroup (measured: 64/128 threads beat 256/512 -- a workgroup holds its LDS until its slowest wave is done)
 constexpr int kRaysPerBlock = kTraceThreads / 4;
 
 #define RR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true)
@@ -207,7 +207,7 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     return best;
 }
 
-// grid: (ceil(cap/64), n_seg), block 256 (= 64 rays), dynamic LDS = 4 waves * stack_lds * 16 * 4
+// grid: (ceil(cap/32), n_seg), block 128 (= 32 rays), dynamic LDS = 2 waves * stack_lds * 16 * 4
 template <bool FIRST, bool STATS, bool SPILL>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
 {
