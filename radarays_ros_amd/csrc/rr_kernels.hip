@@ -386,12 +386,12 @@ __device__ inline int signal_cell(double time, double resolution)
     return (int)((double)signal_dist / resolution);
 }
 
-// grid: (ceil(cap/256), n_seg), block 256
+// grid: (ceil(cap/64), n_seg), block 64 (one wave: no workgroup waits for its slowest wave)
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_shade(const Params P, const int pass)
+__global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
 {
     const int seg = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * 64 + threadIdx.x;
     const int cur = pass & 1, nxt = cur ^ 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
     if (j >= count) return;
@@ -978,7 +978,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
 void launch_shade(const Params& P, int pass, hipStream_t s)
 {
     const int cap_p = pass == 0 ? P.n_beam : P.cap;
-    dim3 grid((cap_p + 255) / 256, P.n_seg), block(256);
+    dim3 grid((cap_p + 63) / 64, P.n_seg), block(64);
     if (pass == 0) hipLaunchKernelGGL((k_shade<true>), grid, block, 0, s, P, pass);
     else           hipLaunchKernelGGL((k_shade<false>), grid, block, 0, s, P, pass);
 }
