@@ -410,6 +410,8 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     const int n_seg = n_loc * n_frames;
     if (n_seg == 0) return 0;
     if (n_frames < 1 || n_frames > 32) return fail(c, -3, "frame batch must be 1..32");
+    if (n_frames > 1 && !d_matsets && !c->motion.empty())
+        return fail(c, -3, "a batch of poses cannot be combined with rr_set_motion_poses (one pose table per azimuth sweep): render such frames one by one");
     for (int k = 0; k < 7 * (d_matsets ? 1 : n_frames); k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
     int rc = upload_tables(c); if (rc) return rc;
     const int n_beam = (int)(c->beams.size() / 3);

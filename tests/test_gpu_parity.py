@@ -238,6 +238,17 @@ def test_error_behaviour(native_lib):
     c.set_materials(params.kaist_materials(), [1], 0)
     with pytest.raises(native_lib.RRError, match="object id"):
         c.simulate(scenes.default_pose("box12"), 0, 8)
+    # a batch of poses and a per-azimuth pose table do not combine
+    import torch
+    c.set_materials(params.kaist_materials() + [params.PENETRABLE], s2["object_materials"], 0)
+    c.set_motion_poses(np.tile(scenes.default_pose("box12"), (400, 1)))
+    cols = torch.zeros((2 * 400, 3424), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    with pytest.raises(native_lib.RRError, match="cannot be combined"):
+        c.simulate_batch_columns_device(np.tile(scenes.default_pose("box12"), (2, 1)), 0, 400, cols.data_ptr())
+    c.set_motion_poses(None)
+    c.simulate_batch_columns_device(np.tile(scenes.default_pose("box12"), (2, 1)), 0, 400, cols.data_ptr())
+    c.synchronize()
     c.close()
 
 
