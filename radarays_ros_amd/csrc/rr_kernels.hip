@@ -211,6 +211,9 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
 template <bool FIRST, bool STATS, bool SPILL>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
 {
+    // k_trace is the long pole of a step: its waves go first when they share a SIMD with the
+    // column / shade waves of the other steps in flight (config 2: live launch 135 -> 122 us)
+    __builtin_amdgcn_s_setprio(2);
     extern __shared__ uint32_t lds_stack[];
     // prepared rays of the workgroup, one per lane of wave 0 (a quad would otherwise repeat the
     // pose algebra four times and every wave would issue it for just 16 rays)
