@@ -238,6 +238,14 @@ def test_error_behaviour(native_lib):
     c.set_materials(params.kaist_materials(), [1], 0)
     with pytest.raises(native_lib.RRError, match="object id"):
         c.simulate(scenes.default_pose("box12"), 0, 8)
+    # parameter batch: set count and table shape are checked
+    base = np.asarray([m.astuple() for m in params.kaist_materials()], np.float32)
+    with pytest.raises(native_lib.RRError, match="n_sets must be 1..32"):
+        c.simulate_material_sets(scenes.default_pose("box12"), np.repeat(base[None], 33, axis=0))
+    bad_sets = np.repeat(base[None], 2, axis=0).copy()
+    bad_sets[1, 1, 3] = np.inf
+    with pytest.raises(native_lib.RRError, match="non-finite material"):
+        c.simulate_material_sets(scenes.default_pose("box12"), bad_sets)
     # a batch of poses and a per-azimuth pose table do not combine
     import torch
     c.set_materials(params.kaist_materials() + [params.PENETRABLE], s2["object_materials"], 0)
