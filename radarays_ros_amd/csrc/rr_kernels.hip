@@ -159,24 +159,23 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
             }
             if (nhit > 0) { sp += nhit - 1; cur = nxt; continue; }
         } else {
-            float t = __builtin_inff();
-            uint32_t face = 0xFFFFFFFFu, tri = 0xFFFFFFFFu;
-            if ((uint32_t)q < cnt) {
-                if (STATS) n_tris++;
-                // Moeller-Trumbore, f32, un-fused: bit-identical to the CPU restatement
-                const V3 v0 = { A.x, A.y, A.z }, e1 = { B.x, B.y, B.z }, e2 = { C.x, C.y, C.z };
-                const V3 pvec = v_cross(d, e2);
-                const float det = v_dot(e1, pvec);
-                const float inv = 1.0f / det;
-                const V3 tvec = v_sub(o, v0);
-                const float u = v_dot(tvec, pvec) * inv;
-                const V3 qvec = v_cross(tvec, e1);
-                const float v = v_dot(d, qvec) * inv;
-                const float tt = v_dot(e2, qvec) * inv;
-                const bool ok = (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
-                                (tt > 0.0f && tt <= range_max);
-                if (ok) { t = tt; face = __float_as_uint(A.w); tri = first + q; }
-            }
+            // Moeller-Trumbore, f32, un-fused: bit-identical to the CPU restatement.  Computed by every
+            // lane (padded triangle arrays keep q >= cnt in bounds), selected at the end: no branches
+            if (STATS) n_tris += ((uint32_t)q < cnt);
+            const V3 v0 = { A.x, A.y, A.z }, e1 = { B.x, B.y, B.z }, e2 = { C.x, C.y, C.z };
+            const V3 pvec = v_cross(d, e2);
+            const float det = v_dot(e1, pvec);
+            const float inv = 1.0f / det;
+            const V3 tvec = v_sub(o, v0);
+            const float u = v_dot(tvec, pvec) * inv;
+            const V3 qvec = v_cross(tvec, e1);
+            const float v = v_dot(d, qvec) * inv;
+            const float tt = v_dot(e2, qvec) * inv;
+            const bool ok = ((uint32_t)q < cnt) && (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
+                            (tt > 0.0f && tt <= range_max);
+            const float t = ok ? tt : __builtin_inff();
+            const uint32_t face = ok ? __float_as_uint(A.w) : 0xFFFFFFFFu;
+            uint32_t tri = ok ? first + q : 0xFFFFFFFFu;
             // quad-wide nearest (t, then lower face index): t is positive or +inf, so the order of
             // (t, face) is the unsigned order of the 64-bit word (t bits : face)
             unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | face;
