@@ -563,3 +563,37 @@ def test_other_azimuth_counts(native_lib, oracle, n_angles, scroll):
     d = image_diff(gf, of, g8, o8)
     assert d["mean_dev"] <= MEAN_DEV_TOL and d["u8_max"] <= 1 and d["u8_mismatch_frac"] <= U8_MISMATCH_TOL, d
     c.close()
+
+
+@pytest.mark.parametrize("kw,n_angles,n_beams", [
+    (dict(n_cells=8192, resolution=0.01, n_reflections=2), 64, 16),                       # widest column the ABI takes
+    (dict(n_reflections=16, ambient_noise=0), 8, 3),                                       # deepest pass count, 3 rays
+    (dict(signal_denoising=1, signal_denoising_triangular_width=256, n_reflections=2), 40, 33),   # widest smear kernel
+    (dict(n_reflections=3), 1000, 1),                                                      # many azimuths, one ray each
+])
+def test_limits_of_the_abi(native_lib, oracle, kw, n_angles, n_beams):
+    """Largest n_cells / smear width / pass count the ABI accepts, odd ray counts, more azimuths than the
+    reference's 400 -- against the oracle."""
+    s = gen.two_room_scene()
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    base = dict(ambient_noise=2)
+    base.update(kw)
+    cfg = params.kaist_preset(**base)
+    rnd = (np.random.RandomState(9).uniform(0, 1, n_angles) * 1000.0).astype(np.float32) if cfg.ambient_noise else None
+    b = golden_beams(n_beams)
+    pose = scenes.default_pose("box12")
+    c = native_lib.Context(0)
+    c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    c.set_materials(mats, s["object_materials"], 0)
+    c.set_config(cfg, n_angles)
+    c.set_beam_samples(b)
+    if rnd is not None:
+        c.set_noise_offsets(rnd)
+    g8, gf, gst = c.simulate(pose, 0, n_angles, want_f32=True)
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
+    o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, b, pose, noise_rnd=rnd,
+                                  n_angles=n_angles)
+    assert gst["overflow"] == 0 and gst["wave_passes"] == ost["wave_passes"] and gst["signals"] == ost["signals"]
+    d = image_diff(gf, of, g8, o8)
+    assert d["mean_dev"] <= MEAN_DEV_TOL and d["u8_max"] <= 1 and d["u8_mismatch_frac"] <= U8_MISMATCH_TOL, d
+    c.close()
