@@ -727,6 +727,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     __syncthreads();
 
     int n_valid_last = 0, n_hit_last = 0;
+    float rmax = 0.0f;          // running maximum of the bins this lane accumulates (max_val, RadarCPU.cpp:404)
     for (int c0 = 0; c0 < S; c0 += kSigChunk) {
         const int n = min(kSigChunk, S - c0);
         if (tid < 2) s_tiles[tid] = 0ull;
@@ -768,6 +769,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 const double wv = *reinterpret_cast<const double*>(wbytes + min(off, W8 - 8u));          \
                 const float nv = (float)((double)acc + (double)__int_as_float((E).y) * wv);              \
                 acc = (off < W8) ? nv : acc;                                                             \
+                rmax = fmaxf(rmax, acc);       /* `if (slice > max_val) max_val = slice` (NaN never wins) */  \
             }
             for (int b0 = 0; b0 < n; b0 += 64) {
                 const int i = b0 + lane;
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                         const int b = __builtin_ctzll(m); m &= m - 1;
                         const int f_b = __builtin_amdgcn_readlane(first, b);
                         const float s_b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.strength), b));
-                        if (g - f_b == 0 && g < n_cells) acc = fmaxf(acc, s_b);               // :439
+                        if (g - f_b == 0 && g < n_cells) { acc = fmaxf(acc, s_b); rmax = fmaxf(rmax, acc); }   // :439-448
                     }
                 }
             }
@@ -824,9 +826,10 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         }
     }
 
-    // max_val: all adds are >= 0, so the running max of RadarCPU.cpp:428-431 is the final max
-    float m = 0.0f;
-    for (int i = tid; i < n_cells; i += kColThreads) m = fmaxf(m, lds_col[i]);
+    // max_val is the RUNNING maximum of RadarCPU.cpp:428-431 / :445-448: the largest value any bin held at
+    // any time.  A multipath echo can be negative (cos^C with an odd C, RadarCPU.cpp:347-353), so a bin may
+    // fall again: the lanes tracked their own running maximum while replaying (rmax), reduce that
+    float m = rmax;
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
     if (lane == 0) s_red[wid] = m;
     __syncthreads();

@@ -361,7 +361,17 @@ def test_frame_batch_equals_single_frames(native_lib):
     c.close()
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+def _fuzz_seeds():
+    """12 seeds + the two that a 600-seed run found (negative multipath echoes: the column maximum is the
+    RUNNING maximum, RadarCPU.cpp:428-431); RR_FUZZ_SEEDS="a:b" adds range(a, b) for a long differential run.
+    Expect about one failure per 300 random scenes from such a run: a wave whose reflected energy lies within
+    1e-7 of the pruning threshold is kept by one libm's acosf and dropped by the other's (seed 377)."""
+    extra = os.environ.get("RR_FUZZ_SEEDS", "")
+    more = list(range(*[int(x) for x in extra.split(":")])) if extra else []
+    return list(range(12)) + [297, 454] + [x for x in more if x not in (297, 454)]
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_random_differential(native_lib, oracle, seed):
     """Randomised scene / materials / config against the oracle (brute-force nearest hit)."""
     rs = np.random.RandomState(1000 + seed)
