@@ -607,3 +607,11 @@ def test_limits_of_the_abi(native_lib, oracle, kw, n_angles, n_beams):
     d = image_diff(gf, of, g8, o8)
     assert d["mean_dev"] <= MEAN_DEV_TOL and d["u8_max"] <= 1 and d["u8_mismatch_frac"] <= U8_MISMATCH_TOL, d
     c.close()
+
+
+def test_stateful_reconfiguration_fuzz(native_lib):
+    """One context reconfigured at random (mesh + builder, materials, config, beams, noise, motion poses,
+    azimuth count) gives the frames a fresh context gives for the same state (tools/fuzz_state.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_state
+    assert fuzz_state.run(iters=60, seed=3, verbose=False) == 0
