@@ -615,3 +615,12 @@ def test_stateful_reconfiguration_fuzz(native_lib):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_state
     assert fuzz_state.run(iters=60, seed=3, verbose=False) == 0
+
+
+def test_trace_fuzz_nasty_geometry(native_lib, oracle):
+    """Nearest hit bit-exact against the brute-force loop on deliberately nasty scenes (mixed triangle
+    scales, shared edges and vertices, duplicated triangles, axis-parallel rays, origins on triangle planes),
+    host and GPU BVH builders (tools/fuzz_trace.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_trace
+    assert fuzz_trace.run(n_seeds=12, first=100, verbose=False) == 0
