@@ -624,3 +624,11 @@ def test_trace_fuzz_nasty_geometry(native_lib, oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_trace
     assert fuzz_trace.run(n_seeds=12, first=100, verbose=False) == 0
+
+
+def test_async_and_batched_entry_points_fuzz(native_lib):
+    """rr_simulate_device over the lanes, frame batches, azimuth-sharded blocks and material sets give the
+    frames of the synchronous rr_simulate, random configs (tools/fuzz_batch.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_batch
+    assert fuzz_batch.run(iters=15, seed=5, verbose=False) == 0
