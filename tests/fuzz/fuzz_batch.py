@@ -3,7 +3,7 @@ rr_simulate_device pipelined over the lanes, rr_simulate_batch_columns_device + 
 azimuth-sharded columns + rr_assemble_blocks_device, rr_simulate_material_sets_device -- random configs,
 bit-exact images expected.  usage: fuzz_batch.py [iterations] [seed]"""
 import sys, os, numpy as np, torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
 from common import golden_beams, GOLDEN
 sys.path.insert(0, GOLDEN)

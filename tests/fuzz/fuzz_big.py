@@ -2,7 +2,7 @@
 trees, spilled/long stacks, penetrable second object): random config / pose / azimuth window against the
 oracle (its own SAH BVH2).  usage: fuzz_big.py [iterations] [seed] [config id]"""
 import sys, os, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
 from oracle import oracle
 from common import golden_beams, image_diff, materials_for, mats_tuple

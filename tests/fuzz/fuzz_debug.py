@@ -1,7 +1,7 @@
 """Re-runs one seed of tests/test_gpu_parity.py::test_random_differential azimuth by azimuth and prints
 where the GPU and the oracle part ways.  usage: fuzz_debug.py SEED"""
 import sys, os, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
 from oracle import oracle
 from common import golden_beams, mats_tuple

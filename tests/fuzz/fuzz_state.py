@@ -3,7 +3,7 @@ beam samples, noise offsets, motion poses), and after every change its frame is 
 a FRESH context given the same state.  Catches stale tables, buffer sizing and lane-reuse mistakes.
 usage: fuzz_state.py [iterations] [seed]"""
 import sys, os, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
 from common import golden_beams, GOLDEN
 sys.path.insert(0, GOLDEN)

@@ -4,7 +4,7 @@ sizes from 1e-3 to 100 m in one scene, coplanar quads sharing edges, duplicated 
 id), axis-parallel rays, rays aimed exactly at vertices / edge midpoints, origins on triangle planes.
 usage: fuzz_trace.py [n_seeds] [first_seed]"""
 import sys, os, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native
 from oracle import oracle
 

@@ -611,8 +611,8 @@ def test_limits_of_the_abi(native_lib, oracle, kw, n_angles, n_beams):
 
 def test_stateful_reconfiguration_fuzz(native_lib):
     """One context reconfigured at random (mesh + builder, materials, config, beams, noise, motion poses,
-    azimuth count) gives the frames a fresh context gives for the same state (tools/fuzz_state.py)."""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    azimuth count) gives the frames a fresh context gives for the same state (tests/fuzz/fuzz_state.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz_state
     assert fuzz_state.run(iters=60, seed=3, verbose=False) == 0
 
@@ -620,15 +620,15 @@ def test_stateful_reconfiguration_fuzz(native_lib):
 def test_trace_fuzz_nasty_geometry(native_lib, oracle):
     """Nearest hit bit-exact against the brute-force loop on deliberately nasty scenes (mixed triangle
     scales, shared edges and vertices, duplicated triangles, axis-parallel rays, origins on triangle planes),
-    host and GPU BVH builders (tools/fuzz_trace.py)."""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    host and GPU BVH builders (tests/fuzz/fuzz_trace.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz_trace
     assert fuzz_trace.run(n_seeds=12, first=100, verbose=False) == 0
 
 
 def test_async_and_batched_entry_points_fuzz(native_lib):
     """rr_simulate_device over the lanes, frame batches, azimuth-sharded blocks and material sets give the
-    frames of the synchronous rr_simulate, random configs (tools/fuzz_batch.py)."""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    frames of the synchronous rr_simulate, random configs (tests/fuzz/fuzz_batch.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz_batch
     assert fuzz_batch.run(iters=15, seed=5, verbose=False) == 0
