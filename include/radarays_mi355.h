@@ -160,6 +160,12 @@ int rr_simulate_columns_device(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_
 int rr_simulate_batch_columns_device(rr_ctx* ctx, const float* poses, int n_frames, int az_begin, int az_end,
                                      uint8_t* d_cols_u8, void* stream);
 
+/* Whole frames of n_frames (1..32) poses in one set of launches, everything on `stream` (no internal
+ * streams: callers that want several batches in flight issue them on several streams, 4 is the measured
+ * optimum): d_imgs_u8 = [n_frames][n_cells][n_angles].  The throughput entry point for offline generation
+ * from C/C++ (tools/cpp_bench.cpp: 41k images/s at config 2 with 4 poses per call on 4 streams). */
+int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint8_t* d_imgs_u8, void* stream);
+
 /* Assemble the mono8 image from column-major columns, applying scroll_image
  * (RadarCPU.cpp:457): d_img[c][(scroll + a) % n_angles] = d_cols[a][c].
  * Device buffers, asynchronous on `stream`. */

@@ -685,6 +685,33 @@ int rr_simulate_batch_columns_device(rr_ctx* c, const float* poses, int n_frames
     return 0;
 }
 
+int rr_simulate_batch_device(rr_ctx* c, const float* poses, int n_frames, uint8_t* d_imgs_u8, void* stream)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!poses || !d_imgs_u8) return fail(c, -3, "rr_simulate_batch_device: null poses/output");
+    if (n_frames < 1 || n_frames > 32) return fail(c, -3, "rr_simulate_batch_device: n_frames must be 1..32");
+    RR_HIP(c, hipSetDevice(c->device));
+    const rr_config& g = c->cfg;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = upload_tables(c); if (rc) return rc;
+    const size_t li = c->next_lane++ % c->lanes.size();
+    Lane& L = c->lanes[li];
+    c->last_lane = li;
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
+    if (L.buf_seg < n_frames * g.n_angles) {
+        RR_HIP(c, hipDeviceSynchronize());      // buffers of this lane may still be read by an earlier step
+        rc = ensure_frame_buffers(c, L, n_frames * g.n_angles, false); if (rc) return rc;
+    }
+    rc = run_frame(c, L, poses, 0, g.n_angles, L.d_cols_u8.p, nullptr, s, n_frames); if (rc) return rc;
+    { TimedScope t(c, s, "assemble");
+      launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
+                         (size_t)g.n_angles * g.n_cells, n_frames, (size_t)g.n_angles * g.n_cells); }
+    RR_HIP(c, hipGetLastError());
+    RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+    L.pending_consume = true;
+    return 0;
+}
+
 int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets,
                                      uint8_t* d_imgs_u8, void* stream)
 {

@@ -18,7 +18,7 @@ SYMBOLS = [
     "rr_set_mesh", "rr_set_mesh_gpu", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
     "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device", "rr_simulate_batch_columns_device",
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
-    "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_synchronize", "rr_get_stats",
+    "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
     "rr_get_kernel_time",
 ]
@@ -109,6 +109,7 @@ def lib():
     L.rr_simulate_device.argtypes = [vp, vp, vp, vp]
     L.rr_simulate_material_sets_device.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.rr_simulate_material_sets.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.rr_simulate_batch_device.argtypes = [vp, vp, C.c_int, vp, vp]
     L.rr_synchronize.argtypes = [vp, vp]
     L.rr_get_stats.argtypes = [vp, C.POINTER(RRStats)]
     L.rr_set_stats_mode.argtypes = [vp, C.c_int]
@@ -241,6 +242,11 @@ class Context:
         p = np.ascontiguousarray(pose, np.float32)
         self._ck(self._L.rr_simulate_columns_device(self._h, p.ctypes.data, az_begin, az_end,
                                                     d_cols_u8_ptr, d_cols_f32_ptr, stream))
+
+    def simulate_batch_device(self, poses, d_imgs_ptr, stream=None):
+        """Whole frames of up to 32 poses in one set of launches on `stream`: images [n][n_cells][n_angles] in HBM."""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ck(self._L.rr_simulate_batch_device(self._h, p.ctypes.data, len(p), d_imgs_ptr, stream))
 
     def simulate_batch_columns_device(self, poses, az_begin, az_end, d_cols_u8_ptr, stream=None):
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)

@@ -44,6 +44,11 @@ def run(iters=20, seed=0, verbose=True):
         c.assemble_frames_device(cols.data_ptr(), 400, 400 * C, K, 400 * C, imgs.data_ptr(), sp)
         c.synchronize(sp); torch.cuda.synchronize()
         if not np.array_equal(imgs.cpu().numpy(), ref): what.append("batch_columns")
+        # (b2) whole frames in one call
+        imgs.zero_(); torch.cuda.synchronize()
+        c.simulate_batch_device(poses, imgs.data_ptr(), sp)
+        c.synchronize(sp); torch.cuda.synchronize()
+        if not np.array_equal(imgs.cpu().numpy(), ref): what.append("batch_device")
         # (c) sharded: W ranks' blocks of one frame, assembled from [rank][n_loc][C]
         W = int(rs.choice([2, 4, 8])); nl = 400 // W
         blocks = torch.zeros((W, nl, C), dtype=torch.uint8, device=dev); one = torch.zeros((C, 400), dtype=torch.uint8, device=dev)

@@ -62,8 +62,7 @@ int main(int argc, char** argv)
     hipDeviceSynchronize();
     t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < steps; k++) {
-        CK(rr_simulate_batch_columns_device(c, &poses[7 * (k % (32 - batch + 1))], batch, 0, cfg.n_angles, d_cols + (size_t)(k % 4) * 8 * npx, st[k % 4]));
-        CK(rr_assemble_frames_device(c, d_cols + (size_t)(k % 4) * 8 * npx, cfg.n_angles, npx, batch, npx, d_img + (size_t)(k % 4) * 8 * npx, st[k % 4]));
+        CK(rr_simulate_batch_device(c, &poses[7 * (k % (32 - batch + 1))], batch, d_img + (size_t)(k % 4) * 8 * npx, st[k % 4]));
     }
     t1 = std::chrono::steady_clock::now();
     hipDeviceSynchronize();
