@@ -632,3 +632,11 @@ def test_async_and_batched_entry_points_fuzz(native_lib):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz_batch
     assert fuzz_batch.run(iters=15, seed=5, verbose=False) == 0
+
+
+def test_differential_fuzz_motion_denoisers_azimuth_counts(native_lib, oracle):
+    """Per-azimuth pose tables, azimuth counts 7..400, every denoiser up to width 256, all noise modes, GPU-built
+    trees, against the oracle (tests/fuzz/fuzz_diff2.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
+    import fuzz_diff2
+    assert fuzz_diff2.run(n=12, seed=42, verbose=False) == 0
