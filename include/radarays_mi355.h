@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 1
+#define RR_ABI_VERSION 2
 
 typedef struct rr_ctx rr_ctx;
 
@@ -188,10 +188,11 @@ int rr_assemble_blocks_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, 
  * image k is bit-identical to rr_set_materials(sets[k]) + rr_simulate_device(pose).
  * d_imgs_u8: [n_sets][n_cells][n_angles] in HBM, stream-ordered like rr_simulate_device. */
 int rr_simulate_material_sets_device(rr_ctx* ctx, const float pose[7], const rr_material* sets, int n_sets,
+                                     size_t n_materials /* per set; must equal rr_set_materials' count */,
                                      uint8_t* d_imgs_u8, void* stream);
 /* Same with a host output buffer (synchronous). */
 int rr_simulate_material_sets(rr_ctx* ctx, const float pose[7], const rr_material* sets, int n_sets,
-                              uint8_t* out_imgs_u8);
+                              size_t n_materials, uint8_t* out_imgs_u8);
 
 /* All frames of a multi-frame step in ONE launch: frame j reads its columns frame_stride bytes after
  * frame j-1 (block addressing as above) and writes image j of d_imgs_u8 [n_frames][n_cells][n_angles]. */
@@ -202,7 +203,10 @@ int rr_assemble_frames_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, 
  * column buffer + rr_assemble_image_device into d_img_u8.  Asynchronous. */
 int rr_simulate_device(rr_ctx* ctx, const float pose_qxyzw_t[7], uint8_t* d_img_u8, void* stream);
 
-/* Blocks until `stream` (NULL = ctx stream) is idle. */
+/* Blocks until `stream` (NULL = ctx stream) and the ctx's own frame lanes are idle, then reports what
+ * the asynchronous (*_device) entry points could not: -7 if any frame enqueued since the last call
+ * exceeded its wave/signal queue capacity, -8 if one met an object/material id outside the tables
+ * (such a frame is truncated; the synchronous rr_simulate returns the same codes itself). */
 int rr_synchronize(rr_ctx* ctx, void* stream);
 
 /* Counters of the last frame (synchronises the ctx stream). */

@@ -153,7 +153,7 @@ public:
         }
         const size_t npx = (size_t)m_cfg.n_cells * m_n_angles;
         std::vector<uint8_t> px(sets.size() * npx);
-        if (rr_simulate_material_sets(m_ctx, Tsm_last, flat.data(), (int)sets.size(), px.data())) { fail(); return out; }
+        if (rr_simulate_material_sets(m_ctx, Tsm_last, flat.data(), (int)sets.size(), n_mat, px.data())) { fail(); return out; }
         for (size_t k = 0; k < sets.size(); k++) {
             ImagePtr msg = std::make_shared<Image>();
             msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;

@@ -68,6 +68,7 @@ struct Lane {
     DevBuf<SigRec> d_sigtmp, d_sig;
     DevBuf<float> d_hit_t, d_cols_f32;
     DevBuf<Counters> d_counters;
+    DevBuf<uint32_t> d_sticky;    // error bits of ALL frames since the last rr_synchronize / rr_get_stats (async entry points)
     DevBuf<uint8_t> d_img_u8;     // host-buffer path: assembled image before the D2H copy
     DevBuf<float> d_img_f32;
     DevBuf<SegStats> d_seg_stats;
@@ -322,7 +323,8 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     RR_HIP(c, L.d_hit_tri.ensure(S * cap));
     RR_HIP(c, L.d_sig.ensure(S * sigcap));
     RR_HIP(c, L.d_sig_count.ensure(S));
-    RR_HIP(c, L.d_counters.ensure(1));
+    if (!L.d_counters.p) { RR_HIP(c, L.d_counters.ensure(1)); RR_HIP(c, hipMemset(L.d_counters.p, 0, sizeof(Counters))); }
+    if (!L.d_sticky.p) { RR_HIP(c, L.d_sticky.ensure(1)); RR_HIP(c, hipMemset(L.d_sticky.p, 0, sizeof(uint32_t))); }
     RR_HIP(c, L.d_seg_stats.ensure(S * (size_t)std::max(1, g.n_reflections)));
     RR_HIP(c, L.d_cols_u8.ensure(S * g.n_cells));
     if (want_f32) RR_HIP(c, L.d_cols_f32.ensure(S * g.n_cells));
@@ -335,6 +337,24 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     else RR_HIP(c, L.d_spill.ensure(1));
     L.buf_seg = n_seg; L.buf_cap = cap; L.buf_sigcap = sigcap; L.buf_cells = g.n_cells;
     return 0;
+}
+
+// Size the lane's frame buffers for n_seg segments under the CURRENT config.  This is the one place
+// that decides whether the buffers fit (segments, wave / signal capacity, n_cells, traversal stack):
+// every entry point sizes through here BEFORE it takes a pointer into the lane, and run_frame()
+// resolves "the lane's own column buffer" only after it -- a reallocation can never leave a caller
+// with a stale pointer.  Frames still in flight may use the old buffers: drain the device first.
+int prepare_lane(rr_ctx* c, Lane& L, int n_seg, bool want_f32 = false)
+{
+    const rr_config& g = c->cfg;
+    const int n_beam = (int)(c->beams.size() / 3);
+    const int cap = wave_capacity(g, n_beam);
+    const bool fits = L.buf_seg >= n_seg && cap == L.buf_cap && g.n_cells == L.buf_cells &&
+                      signal_capacity(g, n_beam, cap) == L.buf_sigcap &&
+                      (!want_f32 || (L.d_cols_f32.p && L.d_cols_f32.n >= (size_t)L.buf_seg * g.n_cells));
+    if (fits) return 0;
+    RR_HIP(c, hipDeviceSynchronize());
+    return ensure_frame_buffers(c, L, std::max(n_seg, L.buf_seg), want_f32);
 }
 
 void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begin, int n_seg,
@@ -354,7 +374,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     }
     P.refpos = L.d_refpos.p;
     P.cflag = L.d_cflag.p; P.sigtmp = L.d_sigtmp.p; P.hit_t = L.d_hit_t.p; P.hit_tri = L.d_hit_tri.p;
-    P.sig = L.d_sig.p; P.sig_count = L.d_sig_count.p; P.spill = L.d_spill.p; P.counters = L.d_counters.p; P.seg_stats = L.d_seg_stats.p;
+    P.sig = L.d_sig.p; P.sig_count = L.d_sig_count.p; P.spill = L.d_spill.p; P.counters = L.d_counters.p; P.sticky = L.d_sticky.p; P.seg_stats = L.d_seg_stats.p;
     P.cols_u8 = d_cols_u8; P.cols_f32 = d_cols_f32;
     P.q_sm = { pose[0], pose[1], pose[2], pose[3] };
     P.t_sm = { pose[4], pose[5], pose[6] };
@@ -401,8 +421,8 @@ int check_ready(rr_ctx* c)
 }
 
 int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
-              uint8_t* d_cols_u8, float* d_cols_f32, hipStream_t s, int n_frames = 1,
-              const float4* d_matsets = nullptr, int mat_stride = 0)
+              uint8_t* d_cols_u8 /* null: the lane's own buffer */, float* d_cols_f32, hipStream_t s, int n_frames = 1,
+              const float4* d_matsets = nullptr, int mat_stride = 0, bool lane_f32 = false)
 {
     const rr_config& g = c->cfg;
     if (az_begin < 0 || az_end > g.n_angles || az_begin > az_end) return fail(c, -3, "azimuth range out of bounds");
@@ -414,12 +434,9 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         return fail(c, -3, "a batch of poses cannot be combined with rr_set_motion_poses (one pose table per azimuth sweep): render such frames one by one");
     for (int k = 0; k < 7 * (d_matsets ? 1 : n_frames); k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
     int rc = upload_tables(c); if (rc) return rc;
-    const int n_beam = (int)(c->beams.size() / 3);
-    const int cap = wave_capacity(g, n_beam);
-    if (n_seg > L.buf_seg || cap != L.buf_cap || g.n_cells != L.buf_cells ||
-        signal_capacity(g, n_beam, cap) != L.buf_sigcap) {
-        rc = ensure_frame_buffers(c, L, std::max(n_seg, L.buf_seg), false); if (rc) return rc;
-    }
+    rc = prepare_lane(c, L, n_seg, lane_f32); if (rc) return rc;
+    if (!d_cols_u8) d_cols_u8 = L.d_cols_u8.p;       // the lane's own column buffer, valid only from here on
+    if (lane_f32) d_cols_f32 = L.d_cols_f32.p;
     Params P;
     fill_params(c, L, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
     P.n_loc = n_loc; P.n_frames = n_frames;
@@ -524,7 +541,7 @@ void rr_destroy(rr_ctx* c)
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
         L.d_refpos.release();
         L.d_hit_tri.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
-        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
+        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -542,7 +559,9 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     RR_HIP(c, hipSetDevice(c->device));
     Bvh4 bvh; std::string err;
     if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err)) return fail(c, -4, err);
-    RR_HIP(c, hipStreamSynchronize(c->stream));
+    // frames in flight on the lane streams or a caller's stream (all non-blocking: a blocking hipMemcpy
+    // does not order against them) still trace the old tree
+    RR_HIP(c, hipDeviceSynchronize());
     RR_HIP(c, c->d_nodes.ensure(bvh.nodes.size()));
     RR_HIP(c, hipMemcpy(c->d_nodes.p, bvh.nodes.data(), bvh.nodes.size() * sizeof(Node4), hipMemcpyHostToDevice));
     RR_HIP(c, c->d_tris.ensure(bvh.tris.size() + 4));   // +4: a quad may fetch past a short leaf
@@ -551,7 +570,7 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     c->n_nodes = bvh.nodes.size(); c->n_tris = bvh.tris.size();
     c->depth = bvh.depth; c->stack_need = bvh.stack_need;
     c->have_mesh = true;
-    for (Lane& L : c->lanes) { if (L.stream) RR_HIP(c, hipStreamSynchronize(L.stream)); L.buf_seg = 0; }   // stack geometry may have changed
+    for (Lane& L : c->lanes) L.buf_seg = 0;   // stack geometry may have changed
     return 0;
 }
 
@@ -612,6 +631,17 @@ int rr_set_config(rr_ctx* c, const rr_config* cfg)
     if (w < 0 || w > 256) return fail(c, -3, "rr_set_config: smear width must be in [0, 256]");
     if (cfg->ambient_noise < 0 || cfg->ambient_noise > 2) return fail(c, -3, "rr_set_config: ambient_noise must be 0..2");
     if (!(cfg->resolution > 0.0)) return fail(c, -3, "rr_set_config: resolution must be > 0");
+    // mode = (int)(fraction * width) indexes the weight table (RadarCPU.cpp:48-93): the reference's
+    // sliders keep the fraction in [0, 1) (cfg/RadarModel.cfg:47-51); anything else would read outside it.
+    // fraction * width < 1 (mode 0) is accepted and gives the reference's 0/0 weights
+    const double mf = cfg->signal_denoising == 1 ? cfg->signal_denoising_triangular_mode
+                    : cfg->signal_denoising == 2 ? cfg->signal_denoising_gaussian_mode
+                    : cfg->signal_denoising == 3 ? cfg->signal_denoising_mb_mode : 0.0;
+    if (!(mf >= 0.0 && mf < 1.0)) return fail(c, -3, "rr_set_config: denoising mode fraction must be in [0, 1)");
+    // tfar of the ray cast; must stay far below the coordinate that marks an empty BVH child (3e38)
+    if (!(cfg->range_max > 0.0f && cfg->range_max <= 1.0e30f)) return fail(c, -3, "rr_set_config: range_max must be in (0, 1e30]");
+    if (!std::isfinite(cfg->wave_energy_threshold) || !std::isfinite(cfg->theta_min) || !std::isfinite(cfg->theta_inc))
+        return fail(c, -3, "rr_set_config: non-finite wave_energy_threshold / theta_min / theta_inc");
     if (c->have_cfg && std::memcmp(&c->cfg, cfg, sizeof(rr_config)) == 0) return 0;
     c->cfg = *cfg;
     c->have_cfg = true; c->tables_dirty |= rr_ctx::D_CFG;
@@ -698,11 +728,7 @@ int rr_simulate_batch_device(rr_ctx* c, const float* poses, int n_frames, uint8_
     Lane& L = c->lanes[li];
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
-    if (L.buf_seg < n_frames * g.n_angles) {
-        RR_HIP(c, hipDeviceSynchronize());      // buffers of this lane may still be read by an earlier step
-        rc = ensure_frame_buffers(c, L, n_frames * g.n_angles, false); if (rc) return rc;
-    }
-    rc = run_frame(c, L, poses, 0, g.n_angles, L.d_cols_u8.p, nullptr, s, n_frames); if (rc) return rc;
+    rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames); if (rc) return rc;
     { TimedScope t(c, s, "assemble");
       launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
                          (size_t)g.n_angles * g.n_cells, n_frames, (size_t)g.n_angles * g.n_cells); }
@@ -713,12 +739,14 @@ int rr_simulate_batch_device(rr_ctx* c, const float* poses, int n_frames, uint8_
 }
 
 int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets,
-                                     uint8_t* d_imgs_u8, void* stream)
+                                     size_t n_materials, uint8_t* d_imgs_u8, void* stream)
 {
     int rc = check_ready(c); if (rc) return rc;
     if (!pose || !sets || !d_imgs_u8) return fail(c, -3, "rr_simulate_material_sets_device: null pose/sets/output");
     if (n_sets < 1 || n_sets > 32) return fail(c, -3, "rr_simulate_material_sets_device: n_sets must be 1..32");
     const size_t n_mat = c->materials.size();
+    if (n_materials != n_mat)
+        return fail(c, -3, "rr_simulate_material_sets_device: every set must hold as many materials as the table given to rr_set_materials");
     for (size_t i = 0; i < (size_t)n_sets * n_mat; i++)
         if (!std::isfinite(sets[i].velocity) || !std::isfinite(sets[i].ambient) || !std::isfinite(sets[i].diffuse) ||
             !std::isfinite(sets[i].specular))
@@ -732,15 +760,14 @@ int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_ma
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     static_assert(sizeof(rr_material) == sizeof(float4), "rr_material is {velocity, ambient, diffuse, specular}");
-    if (L.d_matsets.n < (size_t)n_sets * n_mat || L.d_cols_u8.n < (size_t)n_sets * g.n_angles * g.n_cells ||
-        L.buf_seg < n_sets * g.n_angles) {
-        RR_HIP(c, hipDeviceSynchronize());      // buffers of this lane may still be read by an earlier step
+    if (L.d_matsets.n < (size_t)n_sets * n_mat) {
+        RR_HIP(c, hipDeviceSynchronize());      // the table of this lane may still be read by an earlier step
         RR_HIP(c, L.d_matsets.ensure((size_t)n_sets * n_mat));
-        rc = ensure_frame_buffers(c, L, std::max(n_sets * g.n_angles, L.buf_seg), false); if (rc) return rc;
     }
+    rc = prepare_lane(c, L, n_sets * g.n_angles); if (rc) return rc;
     // pageable source: the copy is staged before the call returns, the caller's array is free again
     RR_HIP(c, hipMemcpyAsync(L.d_matsets.p, sets, (size_t)n_sets * n_mat * sizeof(float4), hipMemcpyHostToDevice, s));
-    rc = run_frame(c, L, pose, 0, g.n_angles, L.d_cols_u8.p, nullptr, s, n_sets, L.d_matsets.p, (int)n_mat); if (rc) return rc;
+    rc = run_frame(c, L, pose, 0, g.n_angles, nullptr, nullptr, s, n_sets, L.d_matsets.p, (int)n_mat); if (rc) return rc;
     { TimedScope t(c, s, "assemble");
       launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
                          (size_t)g.n_angles * g.n_cells, n_sets, (size_t)g.n_angles * g.n_cells); }
@@ -750,7 +777,8 @@ int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_ma
     return 0;
 }
 
-int rr_simulate_material_sets(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets, uint8_t* out_imgs_u8)
+int rr_simulate_material_sets(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets, size_t n_materials,
+                              uint8_t* out_imgs_u8)
 {
     if (!c) return -1;
     if (!out_imgs_u8) return fail(c, -3, "rr_simulate_material_sets: null output");
@@ -758,11 +786,12 @@ int rr_simulate_material_sets(rr_ctx* c, const float pose[7], const rr_material*
     RR_HIP(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)n_sets * c->cfg.n_cells * c->cfg.n_angles;
     RR_HIP(c, c->d_param_imgs.ensure(bytes));
-    int rc = rr_simulate_material_sets_device(c, pose, sets, n_sets, c->d_param_imgs.p, c->stream); if (rc) return rc;
+    int rc = rr_simulate_material_sets_device(c, pose, sets, n_sets, n_materials, c->d_param_imgs.p, c->stream); if (rc) return rc;
     RR_HIP(c, hipMemcpyAsync(out_imgs_u8, c->d_param_imgs.p, bytes, hipMemcpyDeviceToHost, c->stream));
     RR_HIP(c, hipStreamSynchronize(c->stream));
     Counters h;
     RR_HIP(c, hipMemcpy(&h, c->lanes[c->last_lane].d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.overflow) RR_HIP(c, hipMemset(c->lanes[c->last_lane].d_sticky.p, 0, sizeof(uint32_t)));
     if (h.overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
     if (h.overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
     return 0;
@@ -820,8 +849,7 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
     if (c->lanes.size() == 1) {
         Lane& L = c->lanes[0];
         c->last_lane = 0;
-        if (L.buf_seg < A) { rc = ensure_frame_buffers(c, L, A, false); if (rc) return rc; }
-        rc = run_frame(c, L, pose, 0, A, L.d_cols_u8.p, nullptr, user); if (rc) return rc;
+        rc = run_frame(c, L, pose, 0, A, nullptr, nullptr, user); if (rc) return rc;
         return rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user);
     }
     // Frame pipelining: trace/shade/scan/column of this frame run on the lane's own stream
@@ -831,9 +859,8 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
     const size_t li = c->next_stream_lane++ % (size_t)c->stream_lanes;
     Lane& L = c->lanes[li];
     c->last_lane = li;
-    if (L.buf_seg < A) { rc = ensure_frame_buffers(c, L, A, false); if (rc) return rc; }
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(L.stream, L.ev_consumed, 0));
-    rc = run_frame(c, L, pose, 0, A, L.d_cols_u8.p, nullptr, L.stream); if (rc) return rc;
+    rc = run_frame(c, L, pose, 0, A, nullptr, nullptr, L.stream); if (rc) return rc;
     RR_HIP(c, hipEventRecord(L.ev_ready, L.stream));
     RR_HIP(c, hipStreamWaitEvent(user, L.ev_ready, 0));
     rc = rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user); if (rc) return rc;
@@ -848,6 +875,17 @@ int rr_synchronize(rr_ctx* c, void* stream)
     RR_HIP(c, hipSetDevice(c->device));
     for (Lane& L : c->lanes) RR_HIP(c, hipStreamSynchronize(L.stream));
     RR_HIP(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+    // error bits of every frame the asynchronous entry points enqueued since the last call (a frame that
+    // overflowed its wave queue or met a bad material id is truncated, never silently)
+    uint32_t bits = 0;
+    for (Lane& L : c->lanes) {
+        if (!L.d_sticky.p) continue;
+        uint32_t b = 0;
+        RR_HIP(c, hipMemcpy(&b, L.d_sticky.p, sizeof(b), hipMemcpyDeviceToHost));
+        if (b) { bits |= b; RR_HIP(c, hipMemset(L.d_sticky.p, 0, sizeof(b))); }
+    }
+    if (bits & 1u) return fail(c, -7, "wave/signal queue capacity exceeded in a frame since the last rr_synchronize; raise rr_config.max_waves_per_azimuth");
+    if (bits & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials (a frame since the last rr_synchronize)");
     return 0;
 }
 
@@ -890,9 +928,7 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
     Lane& L = c->lanes[0];
     c->last_lane = 0;
     RR_HIP(c, hipDeviceSynchronize());
-    rc = ensure_frame_buffers(c, L, std::max(n_seg, L.buf_seg), out_f32 != nullptr); if (rc) return rc;
-    if (out_f32) RR_HIP(c, L.d_cols_f32.ensure((size_t)L.buf_seg * g.n_cells));
-    rc = run_frame(c, L, pose, az_begin, az_end, L.d_cols_u8.p, out_f32 ? L.d_cols_f32.p : nullptr, c->stream);
+    rc = run_frame(c, L, pose, az_begin, az_end, nullptr, nullptr, c->stream, 1, nullptr, 0, out_f32 != nullptr);
     if (rc) return rc;
     if (n_seg == g.n_angles) {
         // whole frame: transpose on the GPU, one D2H copy straight into the caller's row-major buffer
@@ -932,6 +968,7 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
         RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
         overflow = h.overflow;
     }
+    if (overflow) RR_HIP(c, hipMemset(L.d_sticky.p, 0, sizeof(uint32_t)));   // reported here, not again by rr_synchronize
     if (overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
     if (overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
     return 0;

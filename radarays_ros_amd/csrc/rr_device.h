@@ -106,6 +106,7 @@ struct Params {
     uint32_t* sig_count;         // [n_seg]
     uint32_t* spill;             // traversal stack spill [depth][threads]
     Counters* counters;
+    uint32_t* sticky;            // error bits OR-ed over all frames of the lane (read + cleared by rr_synchronize)
     SegStats* seg_stats;         // [n_passes][n_seg]
     uint8_t* cols_u8;            // [n_seg][n_cells]
     float* cols_f32;             // optional

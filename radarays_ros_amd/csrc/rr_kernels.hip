@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
         }
         if (ok && mat_refr >= (uint32_t)P.n_materials) ok = false;
         if (!ok) {
-            atomicOr(&P.counters->overflow, 2u);
+            atomicOr(&P.counters->overflow, 2u); atomicOr(P.sticky, 2u);
         } else {
             const float4 m = P.materials[(size_t)(seg / P.n_loc) * P.mat_stride + mat_refr];
             const float v_refraction = (mat != mat_refr) ? m.x : (float)0.3;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
             }
         }
     }
-    if (__syncthreads_or((int)ovf) && threadIdx.x == 0) atomicOr(&P.counters->overflow, 1u);
+    if (__syncthreads_or((int)ovf) && threadIdx.x == 0) { atomicOr(&P.counters->overflow, 1u); atomicOr(P.sticky, 1u); }
     if (threadIdx.x == 0) {
         P.count[nxt][seg] = (uint32_t)min(n_child, P.cap);
         P.sig_count[seg] = (uint32_t)min(n_sig, P.sigcap);

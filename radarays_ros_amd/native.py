@@ -107,8 +107,8 @@ def lib():
     L.rr_assemble_blocks_device.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, vp]
     L.rr_assemble_frames_device.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_size_t, vp, vp]
     L.rr_simulate_device.argtypes = [vp, vp, vp, vp]
-    L.rr_simulate_material_sets_device.argtypes = [vp, vp, vp, C.c_int, vp, vp]
-    L.rr_simulate_material_sets.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.rr_simulate_material_sets_device.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, vp, vp]
+    L.rr_simulate_material_sets.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, vp]
     L.rr_simulate_batch_device.argtypes = [vp, vp, C.c_int, vp, vp]
     L.rr_synchronize.argtypes = [vp, vp]
     L.rr_get_stats.argtypes = [vp, C.POINTER(RRStats)]
@@ -274,7 +274,7 @@ class Context:
         """n_sets material tables, one pose -> images [n_sets][n_cells][n_angles] in HBM."""
         a = self._material_sets(sets)
         p = np.ascontiguousarray(pose, dtype=np.float32)
-        self._ck(self._L.rr_simulate_material_sets_device(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], d_imgs_ptr, stream))
+        self._ck(self._L.rr_simulate_material_sets_device(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], a.shape[1], d_imgs_ptr, stream))
 
     def simulate_material_sets(self, pose, sets):
         """Host-buffer variant: returns a uint8 array [n_sets][n_cells][n_angles]."""
@@ -282,7 +282,7 @@ class Context:
         p = np.ascontiguousarray(pose, dtype=np.float32)
         n_cells = self.cfg.n_cells if self.cfg is not None else 1
         out = np.zeros((a.shape[0], n_cells, self.n_angles), dtype=np.uint8)
-        self._ck(self._L.rr_simulate_material_sets(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], out.ctypes.data))
+        self._ck(self._L.rr_simulate_material_sets(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data))
         return out
 
     def simulate_device(self, pose, d_img_ptr, stream=None):

@@ -82,6 +82,33 @@ def run(iters=100, seed=0, verbose=True):
             want, werr = None, str(e)
         f.close()
         ok = (err is None) == (werr is None) and (got is None or np.array_equal(got, want))
+        # the asynchronous / batched entry points of the SAME long-lived context, after the same
+        # reconfiguration (lane buffers sized for an earlier config: n_cells / capacity growth must
+        # never leave a stale pointer behind) -- compared with the fresh context's frame
+        dev_bad = []
+        if want is not None and err is None:
+            import torch
+            A, Cc = state["n_angles"], state["cfg"].n_cells
+            img = torch.zeros((2, Cc, A), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            sp = torch.cuda.current_stream().cuda_stream
+            for lane in range(3):          # rr_simulate_device rotates over its lane streams: visit them all
+                img.zero_()
+                torch.cuda.synchronize()
+                c.simulate_device(pose, img[0].data_ptr(), sp)
+                c.synchronize(sp)
+                if not np.array_equal(img[0].cpu().numpy(), want): dev_bad.append("simulate_device[%d]" % lane)
+            if not state["motion"]:
+                for lane in range(4):
+                    img.zero_()
+                    torch.cuda.synchronize()
+                    c.simulate_batch_device(np.stack([pose, pose]), img.data_ptr(), sp)
+                    c.synchronize(sp)
+                    g2 = img.cpu().numpy()
+                    if not (np.array_equal(g2[0], want) and np.array_equal(g2[1], want)): dev_bad.append("simulate_batch_device[%d]" % lane)
+            if dev_bad:
+                ok = False
+                print("device entry points differ:", dev_bad)
         if not ok:
             bad += 1
             print("MISMATCH at iteration", it, "after", what, "state", {k: (v if k not in ("mats", "cfg") else "...") for k, v in state.items()},

@@ -218,6 +218,13 @@ def test_error_behaviour(native_lib):
     c.set_materials(params.kaist_materials(), [1], 0)
     with pytest.raises(native_lib.RRError, match="n_cells"):
         c.set_config(params.kaist_preset(n_cells=0))
+    # the denoiser's mode index must stay inside its weight table; tfar must stay below the empty-child marker
+    for bad_mode in (1.0, 1.5, -0.1, float("nan")):
+        with pytest.raises(native_lib.RRError, match="mode fraction"):
+            c.set_config(params.kaist_preset(signal_denoising_triangular_mode=bad_mode))
+    for bad_range in (0.0, -1.0, 3.0e38, float("inf"), float("nan")):
+        with pytest.raises(native_lib.RRError, match="range_max"):
+            c.set_config(params.kaist_preset(), 400, ray_range_max=bad_range)
     c.set_config(params.kaist_preset(n_reflections=2, ambient_noise=0))
     c.set_beam_samples(golden_beams(8))
     with pytest.raises(native_lib.RRError, match="azimuth range"):
@@ -233,6 +240,14 @@ def test_error_behaviour(native_lib):
     c.set_config(params.kaist_preset(n_reflections=4, ambient_noise=0), 400, max_waves_per_azimuth=9)
     with pytest.raises(native_lib.RRError, match="capacity"):
         c.simulate(scenes.default_pose("box12"), 0, 8)
+    # ... also by the asynchronous entry points: rr_synchronize reports it once, then is clean again
+    import torch
+    dimg = torch.zeros((3424, 400), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    c.simulate_device(scenes.default_pose("box12"), dimg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(native_lib.RRError, match="capacity"):
+        c.synchronize(torch.cuda.current_stream().cuda_stream)
+    c.synchronize(torch.cuda.current_stream().cuda_stream)
     # object id beyond object_materials
     c.set_config(params.kaist_preset(n_reflections=1, ambient_noise=0))
     c.set_materials(params.kaist_materials(), [1], 0)
@@ -242,6 +257,8 @@ def test_error_behaviour(native_lib):
     base = np.asarray([m.astuple() for m in params.kaist_materials()], np.float32)
     with pytest.raises(native_lib.RRError, match="n_sets must be 1..32"):
         c.simulate_material_sets(scenes.default_pose("box12"), np.repeat(base[None], 33, axis=0))
+    with pytest.raises(native_lib.RRError, match="as many materials"):
+        c.simulate_material_sets(scenes.default_pose("box12"), np.repeat(base[None, :1], 2, axis=0))
     bad_sets = np.repeat(base[None], 2, axis=0).copy()
     bad_sets[1, 1, 3] = np.inf
     with pytest.raises(native_lib.RRError, match="non-finite material"):
