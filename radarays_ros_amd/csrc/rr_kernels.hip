@@ -636,18 +636,38 @@ __device__ inline double2 p_grad_coef(int hash)
     return make_double2(a, b);
 }
 __device__ inline double p_grad2(const double2 g, double x, double y) { return g.x * x + g.y * y; }
-// perlin_noise(x, y, z = 0) of image_algorithms.h:69-106 with the permutation table in LDS.
+// perlin_noise(x, y, z = 0) of image_algorithms.h:69-106 along ONE image column.
 // For z = 0: Z = 0, w = fade(0) = 0, and lerp(0, a, b) = a + 0*(b - a) = a exactly (b - a is
 // finite), so the z-1 half of the lattice is not evaluated -- bit-identical result.
-__device__ inline double perlin_noise(const unsigned char* pt, const double2* gt, double sx, double sy)
+// Within a column sy is fixed, so Y, y and v = fade(y) are column constants and the two hash
+// chains pt[(pt[X] + Y) & 255], pt[(pt[X] + Y + 1) & 255] depend on the lattice column X only:
+// they are tabulated once per column (257 entries: X + 1 needs no wrap) together with the
+// y-half of the gradient, entry = (a, b * y) resp. (a, b * (y - 1)) -- the same f64 product the
+// reference forms per pixel -- so one evaluation is four 16-B LDS reads off ONE address,
+// four (mul, add) gradients and three lerps.
+constexpr int kPerlinRow = 257;
+struct PerlinCol { double v; const double2* t0; const double2* t1; };   // t0: row y, t1: row y - 1
+__device__ inline void perlin_col_table(const unsigned char* pt, const double2* gt, double sy, double2* t0, double2* t1,
+                                        int tid, int n_threads)
 {
-    const int X = (int)floor(sx) & 255, Y = (int)floor(sy) & 255;
-    const double x = sx - floor(sx), y = sy - floor(sy);
-    const double u = p_fade(x), v = p_fade(y);
-    const int A = pt[X] + Y, AA = pt[A & 255], AB = pt[(A + 1) & 255];
-    const int B = pt[(X + 1) & 255] + Y, BA = pt[B & 255], BB = pt[(B + 1) & 255];
-    return p_lerp(v, p_lerp(u, p_grad2(gt[AA], x, y), p_grad2(gt[BA], x - 1, y)),
-                     p_lerp(u, p_grad2(gt[AB], x, y - 1), p_grad2(gt[BB], x - 1, y - 1)));
+    const int Y = (int)floor(sy) & 255;
+    const double y = sy - floor(sy);
+    for (int e = tid; e < 2 * kPerlinRow; e += n_threads) {
+        const int row = e >= kPerlinRow ? 1 : 0;
+        const int X = (e - row * kPerlinRow) & 255;
+        const double2 g = gt[pt[(pt[X] + Y + row) & 255]];
+        (row ? t1 : t0)[e - row * kPerlinRow] = make_double2(g.x, g.y * (row ? y - 1 : y));
+    }
+}
+__device__ inline double perlin_col(const PerlinCol& pc, double sx)
+{
+    const double fl = floor(sx);
+    const int X = (int)fl & 255;
+    const double x = sx - fl, x1 = x - 1;
+    const double u = p_fade(x);
+    const double2 e00 = pc.t0[X], e10 = pc.t0[X + 1], e01 = pc.t1[X], e11 = pc.t1[X + 1];
+    return p_lerp(pc.v, p_lerp(u, e00.x * x + e00.y, e10.x * x1 + e10.y),
+                        p_lerp(u, e01.x * x + e01.y, e11.x * x1 + e11.y));
 }
 
 // defined variate stream for ambient_noise == 1 (the reference draws from
@@ -696,7 +716,10 @@ constexpr int kColWaves = kColThreads / 64;
 __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 {
     extern __shared__ float lds_col[];              // [n_cells] slice
-    __shared__ SigRec s_sig[kSigChunk];
+    // replay phase: the current chunk of signals; noise phase: the four Perlin column tables
+    __shared__ __align__(16) unsigned char s_union[4 * kPerlinRow * sizeof(double2)];
+    static_assert(sizeof(s_union) >= kSigChunk * sizeof(SigRec), "signal chunk must fit");
+    SigRec* s_sig = reinterpret_cast<SigRec*>(s_union);
     __shared__ double s_w[256];                     // smear weights, widened once (the replay multiplies in f64)
     __shared__ unsigned long long s_tiles[2];
     __shared__ float s_red[kColWaves];
@@ -840,6 +863,16 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     const int col = (P.scroll + angle_id) % P.n_angles;   // :457 (placement is done by the assemble step)
     const float final_scale = (float)(P.signal_max / (double)max_val);   // :533
     const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[angle_id] : 0.0f;
+    PerlinCol pc1 = { 0.0, nullptr, nullptr }, pc2 = pc1;
+    if (P.ambient_noise == 2) {   // the signal chunk is dead (barriers above): its LDS holds the column tables now
+        double2* tab = reinterpret_cast<double2*>(s_union);
+        const double sy1 = (double)col * 0.05, sy2 = (double)col * 0.2;
+        perlin_col_table(s_perm, s_grad, sy1, tab, tab + kPerlinRow, tid, kColThreads);
+        perlin_col_table(s_perm, s_grad, sy2, tab + 2 * kPerlinRow, tab + 3 * kPerlinRow, tid, kColThreads);
+        pc1 = { p_fade(sy1 - floor(sy1)), tab, tab + kPerlinRow };
+        pc2 = { p_fade(sy2 - floor(sy2)), tab + 2 * kPerlinRow, tab + 3 * kPerlinRow };
+        __syncthreads();
+    }
 
     for (int i = tid; i < n_cells; i += kColThreads) {
         float v = lds_col[i] * P.energy_max_f;   // :453
@@ -850,8 +883,8 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 p = (double)uniform01((uint32_t)(int)rnd, (uint32_t)col, (uint32_t)i);
             } else if (P.ambient_noise == 2) {
                 const double random_begin = (double)rnd;
-                const double p1 = perlin_noise(s_perm, s_grad, random_begin + (double)i * 0.05, (double)col * 0.05);
-                const double p2 = perlin_noise(s_perm, s_grad, random_begin + (double)i * 0.2, (double)col * 0.2);
+                const double p1 = perlin_col(pc1, random_begin + (double)i * 0.05);
+                const double p2 = perlin_col(pc2, random_begin + (double)i * 0.2);
                 p = 0.9 * p1 + 0.1 * p2;
             }
             const float signal_max = max_val;
