@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-A step = one batch of `--frames-per-rank` (default 4) poses per GPU, each rendered to one polar
+A step = one batch of `--frames-per-rank` (default 8) poses per GPU, each rendered to one polar
 image (400 azimuths x 3424 range bins, mono8) of the workload BASELINE.json's metric is
 quoted on (configs[1]): 400 azimuths x 200 rays, 1 ray-cast pass, 100k-triangle synthetic mesh, KAIST parameter preset (cfg/mulran_kaist_dyncfg.yaml)
 including the Perlin ambient-noise stage with injected per-column offsets.  Mesh, BVH,
@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="N>1: one frame per step + all-gather")
     ap.add_argument("--force-slots", action="store_true", help="run the N>1 step loop (with its collective) on one rank (debug)")
     ap.add_argument("--slots", type=int, default=4, help="steps in flight (streams + buffer sets); RR_LANES must be >= slots")
-    ap.add_argument("--frames-per-rank", type=int, default=4,
+    ap.add_argument("--frames-per-rank", type=int, default=8,
                     help="frames each GPU finishes per step (one set of launches); a step = N x this many frames")
     args = ap.parse_args()
 

@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 #define RR_ABI_VERSION 2
+#define RR_MAX_BATCH 64   /* frames (poses or material sets) one call renders in one set of launches */
 
 typedef struct rr_ctx rr_ctx;
 
@@ -153,14 +154,14 @@ int rr_simulate_columns_device(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_
                                uint8_t* d_cols_u8, float* d_cols_f32, void* stream);
 
 /* Frame batch (multi-GPU weak scaling, offline generation): the same azimuth block
- * [az_begin, az_end) of n_frames (1..32) different poses in ONE set of launches.
+ * [az_begin, az_end) of n_frames (1..RR_MAX_BATCH) different poses in ONE set of launches.
  * poses = [n_frames][7]; d_cols_u8 = [n_frames][az_end-az_begin][n_cells].  Kernels then see
  * n_frames x block segments, i.e. a rank that owns 1/N of the azimuths of N frames does the
  * same amount of work per launch as a single GPU does for one whole frame. */
 int rr_simulate_batch_columns_device(rr_ctx* ctx, const float* poses, int n_frames, int az_begin, int az_end,
                                      uint8_t* d_cols_u8, void* stream);
 
-/* Whole frames of n_frames (1..32) poses in one set of launches, everything on `stream` (no internal
+/* Whole frames of n_frames (1..RR_MAX_BATCH) poses in one set of launches, everything on `stream` (no internal
  * streams: callers that want several batches in flight issue them on several streams, 4 is the measured
  * optimum): d_imgs_u8 = [n_frames][n_cells][n_angles].  The throughput entry point for offline generation
  * from C/C++ (tools/cpp_bench.cpp: 41k images/s at config 2 with 4 poses per call on 4 streams). */
@@ -178,7 +179,7 @@ int rr_assemble_image_device(rr_ctx* ctx, const uint8_t* d_cols_u8 /*[n_angles][
 int rr_assemble_blocks_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
                               uint8_t* d_img_u8, void* stream);
 
-/* Parameter batch: n_sets (1..32) material tables, ONE pose -> n_sets images.
+/* Parameter batch: n_sets (1..RR_MAX_BATCH) material tables, ONE pose -> n_sets images.
  * Replaces n_sets round trips of the reference's optimisation loop, where every objective
  * evaluation sends one RadarParams goal to the gen_radar_image action and waits for one image
  * (action/GenRadarImage.action, scripts/radaray_opti.py:170-200; the server side sets

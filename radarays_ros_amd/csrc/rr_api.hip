@@ -429,7 +429,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     const int n_loc = az_end - az_begin;
     const int n_seg = n_loc * n_frames;
     if (n_seg == 0) return 0;
-    if (n_frames < 1 || n_frames > 32) return fail(c, -3, "frame batch must be 1..32");
+    if (n_frames < 1 || n_frames > RR_MAX_BATCH) return fail(c, -3, "frame batch must be 1..64");
     if (n_frames > 1 && !d_matsets && !c->motion.empty())
         return fail(c, -3, "a batch of poses cannot be combined with rr_set_motion_poses (one pose table per azimuth sweep): render such frames one by one");
     for (int k = 0; k < 7 * (d_matsets ? 1 : n_frames); k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
@@ -719,7 +719,7 @@ int rr_simulate_batch_device(rr_ctx* c, const float* poses, int n_frames, uint8_
 {
     int rc = check_ready(c); if (rc) return rc;
     if (!poses || !d_imgs_u8) return fail(c, -3, "rr_simulate_batch_device: null poses/output");
-    if (n_frames < 1 || n_frames > 32) return fail(c, -3, "rr_simulate_batch_device: n_frames must be 1..32");
+    if (n_frames < 1 || n_frames > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_batch_device: n_frames must be 1..64");
     RR_HIP(c, hipSetDevice(c->device));
     const rr_config& g = c->cfg;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -743,7 +743,7 @@ int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_ma
 {
     int rc = check_ready(c); if (rc) return rc;
     if (!pose || !sets || !d_imgs_u8) return fail(c, -3, "rr_simulate_material_sets_device: null pose/sets/output");
-    if (n_sets < 1 || n_sets > 32) return fail(c, -3, "rr_simulate_material_sets_device: n_sets must be 1..32");
+    if (n_sets < 1 || n_sets > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_material_sets_device: n_sets must be 1..64");
     const size_t n_mat = c->materials.size();
     if (n_materials != n_mat)
         return fail(c, -3, "rr_simulate_material_sets_device: every set must hold as many materials as the table given to rr_set_materials");
@@ -782,7 +782,7 @@ int rr_simulate_material_sets(rr_ctx* c, const float pose[7], const rr_material*
 {
     if (!c) return -1;
     if (!out_imgs_u8) return fail(c, -3, "rr_simulate_material_sets: null output");
-    if (n_sets < 1 || n_sets > 32) return fail(c, -3, "rr_simulate_material_sets: n_sets must be 1..32");
+    if (n_sets < 1 || n_sets > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_material_sets: n_sets must be 1..64");
     RR_HIP(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)n_sets * c->cfg.n_cells * c->cfg.n_angles;
     RR_HIP(c, c->d_param_imgs.ensure(bytes));
@@ -816,7 +816,7 @@ int rr_assemble_frames_device(rr_ctx* c, const uint8_t* d_cols_u8, int n_loc, si
     if (!c->have_cfg) return fail(c, -2, "rr_set_config has not been called");
     if (!d_cols_u8 || !d_imgs_u8) return fail(c, -3, "rr_assemble_frames_device: null buffer");
     if (n_loc < 1 || c->cfg.n_angles % n_loc != 0) return fail(c, -3, "rr_assemble_frames_device: n_loc must divide n_angles");
-    if (n_frames < 1 || n_frames > 32) return fail(c, -3, "rr_assemble_frames_device: n_frames must be 1..32");
+    if (n_frames < 1 || n_frames > RR_MAX_BATCH) return fail(c, -3, "rr_assemble_frames_device: n_frames must be 1..64");
     RR_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     { TimedScope t(c, s, "assemble"); launch_assemble_u8(d_cols_u8, d_imgs_u8, c->cfg.n_angles, c->cfg.n_cells, c->cfg.scroll_image, s, n_loc, block_stride, n_frames, frame_stride); }

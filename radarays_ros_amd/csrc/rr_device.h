@@ -116,7 +116,7 @@ struct Params {
     // frame batch: segment s belongs to frame s / n_loc and azimuth az_begin + s % n_loc;
     // frame f > 0 uses batch_poses[f - 1] (frame 0 uses q_sm / t_sm)
     int n_loc, n_frames;
-    float batch_poses[31][7];
+    float batch_poses[63][7];     // RR_MAX_BATCH - 1 (kernel arguments: 1.8 KB of the 4 KB limit)
     int n_beam, cap, sigcap;
     int n_cells, n_angles, n_materials, n_objects, material_id_air;
     int n_passes, record_multi_reflection, record_multi_path;

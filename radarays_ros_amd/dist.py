@@ -86,8 +86,8 @@ class AzimuthShard:
         self.strong = self.collective and (strong or n_angles % world != 0)
         self.fpr = 1 if self.strong else int(frames_per_rank)
         self.frames_per_step = 1 if self.strong else self.fpr * world
-        if self.frames_per_step > 32:
-            raise ValueError("at most 32 frames per step")
+        if self.frames_per_step > 64:      # RR_MAX_BATCH
+            raise ValueError("at most 64 frames per step")
         self.slots = [_Slot(self.frames_per_step, self.fpr, self.n_loc, n_cells, n_angles, device)
                       for _ in range(n_slots)]
         self.last = None

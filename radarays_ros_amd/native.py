@@ -244,7 +244,7 @@ class Context:
                                                     d_cols_u8_ptr, d_cols_f32_ptr, stream))
 
     def simulate_batch_device(self, poses, d_imgs_ptr, stream=None):
-        """Whole frames of up to 32 poses in one set of launches on `stream`: images [n][n_cells][n_angles] in HBM."""
+        """Whole frames of up to 64 (RR_MAX_BATCH) poses in one set of launches on `stream`: images [n][n_cells][n_angles] in HBM."""
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
         self._ck(self._L.rr_simulate_batch_device(self._h, p.ctypes.data, len(p), d_imgs_ptr, stream))
 

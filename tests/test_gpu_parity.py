@@ -255,8 +255,8 @@ def test_error_behaviour(native_lib):
         c.simulate(scenes.default_pose("box12"), 0, 8)
     # parameter batch: set count and table shape are checked
     base = np.asarray([m.astuple() for m in params.kaist_materials()], np.float32)
-    with pytest.raises(native_lib.RRError, match="n_sets must be 1..32"):
-        c.simulate_material_sets(scenes.default_pose("box12"), np.repeat(base[None], 33, axis=0))
+    with pytest.raises(native_lib.RRError, match="n_sets must be 1..64"):
+        c.simulate_material_sets(scenes.default_pose("box12"), np.repeat(base[None], 65, axis=0))
     with pytest.raises(native_lib.RRError, match="as many materials"):
         c.simulate_material_sets(scenes.default_pose("box12"), np.repeat(base[None, :1], 2, axis=0))
     bad_sets = np.repeat(base[None], 2, axis=0).copy()
@@ -374,7 +374,7 @@ def test_frame_batch_equals_single_frames(native_lib):
         one, _, _ = c.simulate(p, b, e)
         assert np.array_equal(block[f].cpu().numpy().T, one[:, b:e]), f
     with pytest.raises(native_lib.RRError, match="frame batch"):
-        c.simulate_batch_columns_device(np.tile(poses[0], (33, 1)), b, e, block.data_ptr(), st)
+        c.simulate_batch_columns_device(np.tile(poses[0], (65, 1)), b, e, block.data_ptr(), st)
     c.close()
 
 
