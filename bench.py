@@ -53,6 +53,9 @@ WORKLOADS = {
     "config3_1M_400x200_4pass": (3, 4, 200),
     "config4_10M_400x1000_4pass": (4, 4, 1000),
     "target_10M_400x200_4pass": (4, 4, 200),
+    # configs[4] minus its BRDF: per-triangle materials (8), 8 passes, 10M triangles -- the Cook-Torrance
+    # model lives on the reference's dev/flex branch, not in the checkout; run with --frames-per-rank 1
+    "config5_10M_400x1000_8pass_pertri": (5, 8, 1000),
 }
 
 

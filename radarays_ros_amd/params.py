@@ -109,5 +109,16 @@ def kaist_materials() -> List[RadarMaterial]:
 # actually occurs (the KAIST table alone never refracts: v = 0)
 PENETRABLE = RadarMaterial(0.1, 0.6, 0.3, 30.0)
 
+def config5_materials() -> List[RadarMaterial]:
+    """Air + the 8 per-triangle materials of SURVEY §8d config 5: four opaque ones (v = 0, like the
+    KAIST wall: reflection only) and four penetrable ones, with spread BRDF parameters.  The BRDF is
+    the checkout's A + B cos^C (the Cook-Torrance family of the dev/flex branch is not in it)."""
+    return [RadarMaterial(0.3, 1.0, 0.0, 1.0),
+            RadarMaterial(0.0, 1.0, 0.0, 3000.0), RadarMaterial(0.0, 0.8, 0.2, 100.0),
+            RadarMaterial(0.0, 0.5, 0.5, 10.0), RadarMaterial(0.0, 0.2, 0.8, 2.0),
+            RadarMaterial(0.1, 0.6, 0.3, 30.0), RadarMaterial(0.15, 0.4, 0.4, 8.0),
+            RadarMaterial(0.2, 0.7, 0.2, 300.0), RadarMaterial(0.25, 0.3, 0.6, 1.0)]
+
+
 N_ANGLES = 400                       # Radar.cpp:29
 WAVE_ENERGY_THRESHOLD = 0.001        # Radar.cpp:24

@@ -134,9 +134,25 @@ def config_scene(config_id):
         return heightfield_room(224)                         # 100,352 + 12 triangles
     if config_id == 3:
         return heightfield_room(708, n_buildings=2000)       # 1,002,528 + 12 + 24,000
-    if config_id in (4, 5):
+    if config_id == 4:
         return heightfield_room(2237, n_buildings=20000)     # 10,008,338 + 12 + 240,000
+    if config_id == 5:
+        # the config-4 mesh with PER-TRIANGLE material ids (8 materials, seed 5)
+        return per_triangle_materials(heightfield_room(2237, n_buildings=20000), 8, seed=5)
     raise ValueError("unknown config %r" % (config_id,))
+
+
+def per_triangle_materials(scene, n_materials=8, seed=5):
+    """Every face becomes its own 'object' class: face_object_id = random id in [0, n_materials),
+    object k -> material k + 1 (material 0 stays air).  This is how the reference expresses
+    per-triangle materials: object_materials[] is indexed by the id the ray cast returns
+    (RadarCPU.cpp:266-271), and the mesh import decides what an object is."""
+    rs = np.random.RandomState(seed)
+    out = dict(scene)
+    out["face_object_id"] = rs.randint(0, n_materials, len(scene["faces"])).astype(np.uint32)
+    out["object_materials"] = list(range(1, n_materials + 1))
+    out["name"] = scene["name"] + "_pertri%d" % n_materials
+    return out
 
 
 def yaw_pose(x, y, z, yaw):

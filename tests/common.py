@@ -21,6 +21,8 @@ def mats_tuple(mats):
 
 
 def materials_for(scene):
+    if "_pertri" in scene.get("name", ""):
+        return params.config5_materials()
     m = params.kaist_materials()
     if max(scene["object_materials"]) >= 2:
         m = m + [params.PENETRABLE]

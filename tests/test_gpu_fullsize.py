@@ -82,3 +82,35 @@ def test_config4_1000_rays(big, native_lib):
     assert img.max() <= 255 and (img > 0).mean() > 0.5      # noise floor fills the image
     again, _, _ = c.simulate(scenes.default_pose(s["name"]))
     assert np.array_equal(img, again)
+
+
+def test_config5_per_triangle_materials_8_passes(big, native_lib, oracle):
+    """configs[4]'s structure at full size: 10M triangles, one of 8 materials PER TRIANGLE (seed 5),
+    8 passes (its Cook-Torrance BRDF is on the reference's dev/flex branch, not in the checkout: the
+    checkout's A + B cos^C is used).  Properties on the whole frame + the oracle on two azimuths."""
+    _, c = big
+    s = scenes.config_scene(5)
+    mats = materials_for(s)
+    assert len(mats) == 9 and len(set(s["face_object_id"].tolist())) == 8
+    c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    c.set_materials(mats, s["object_materials"], 0)
+    cfg = params.kaist_preset(n_reflections=8, ambient_noise=0)
+    c.set_config(cfg)
+    c.set_beam_samples(golden_beams(200))
+    pose = scenes.default_pose(s["name"])
+    full, _, st = c.simulate(pose)
+    assert st["overflow"] == 0
+    # penetrable triangles split the waves: clearly more wave-passes than 8 passes of 80k unsplit rays would
+    # lose to pruning, yet bounded by the doubling bound
+    assert 80000 * 2 < st["wave_passes"] <= 80000 * 255
+    assert np.all(full.max(axis=0) == 79) and not full[0].any()
+    again, _, st2 = c.simulate(pose)
+    assert np.array_equal(full, again) and st2 == st
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=1)
+    for az in ((11, 13), (301, 303)):
+        g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
+        o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg,
+                                      golden_beams(200), pose, az_begin=az[0], az_end=az[1])
+        assert gst["wave_passes"] == ost["wave_passes"] and gst["signals"] == ost["signals"], (gst, ost)
+        d = image_diff(gf[:, az[0]:az[1]], of[:, az[0]:az[1]], g8[:, az[0]:az[1]], o8[:, az[0]:az[1]])
+        assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1, d
