@@ -99,8 +99,8 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     const V3 o = R.o, d = R.d;
     const float idx = R.idx, idy = R.idy, idz = R.idz, oox = R.oox, ooy = R.ooy, ooz = R.ooz;
 
-    Hit best; best.t = __builtin_inff(); best.tri = 0xFFFFFFFFu; best.face = 0xFFFFFFFFu;
-    unsigned long long bestkey = 0x7F800000FFFFFFFFull;   // (+inf : no face)
+    unsigned long long bestkey = 0x7F80000000000000ull;   // (+inf : 0): only a finite t can beat it
+    uint32_t best_first = 0;                              // first triangle of the leaf that holds the best hit
     float tcull = range_max * 1.0001f + 1e-3f;
     int sp = 0;
     uint32_t cur = 0;   // root
@@ -173,27 +173,21 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
             const float tt = v_dot(e2, qvec) * inv;
             const bool ok = ((uint32_t)q < cnt) && (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
                             (tt > 0.0f && tt <= range_max);
-            const float t = ok ? tt : __builtin_inff();
-            const uint32_t face = ok ? __float_as_uint(A.w) : 0xFFFFFFFFu;
-            uint32_t tri = ok ? first + q : 0xFFFFFFFFu;
-            // quad-wide nearest (t, then lower face index): t is positive or +inf, so the order of
-            // (t, face) is the unsigned order of the 64-bit word (t bits : face)
-            unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | face;
-            {
-                unsigned long long k2 = ((unsigned long long)(uint32_t)RR_DPP_I((uint32_t)(key >> 32), RR_QXOR1) << 32) |
-                                        (uint32_t)RR_DPP_I((uint32_t)key, RR_QXOR1);
-                uint32_t r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR1);
-                bool take = k2 < key;
-                key = take ? k2 : key; tri = take ? r2 : tri;
-                k2 = ((unsigned long long)(uint32_t)RR_DPP_I((uint32_t)(key >> 32), RR_QXOR2) << 32) |
-                     (uint32_t)RR_DPP_I((uint32_t)key, RR_QXOR2);
-                r2 = (uint32_t)RR_DPP_I(tri, RR_QXOR2);
-                take = k2 < key;
-                key = take ? k2 : key; tri = take ? r2 : tri;
-            }
+            // quad-wide nearest (t, then lower face index) in two 32-bit rounds: t is positive or +inf, so its
+            // order is the unsigned order of its bits -> minimum over the quad with two DPP mins; then, among
+            // the lanes that hold that minimum, the lowest (face << 2 | lane): the low bits name the winning
+            // lane, i.e. the triangle's slot in the leaf (face < 2^28).  A leaf without a hit yields
+            // (+inf : something), which never beats the initial (+inf : 0).
+            const uint32_t tb = ok ? __float_as_uint(tt) : 0x7F800000u;
+            uint32_t tm = min(tb, (uint32_t)RR_DPP_I(tb, RR_QXOR1));
+            tm = min(tm, (uint32_t)RR_DPP_I(tm, RR_QXOR2));
+            const uint32_t fk = (tb == tm) ? ((__float_as_uint(A.w) << 2) | (uint32_t)q) : 0xFFFFFFFFu;
+            uint32_t fm = min(fk, (uint32_t)RR_DPP_I(fk, RR_QXOR1));
+            fm = min(fm, (uint32_t)RR_DPP_I(fm, RR_QXOR2));
+            const unsigned long long key = ((unsigned long long)tm << 32) | fm;
             if (key < bestkey) {
-                bestkey = key; best.tri = tri;
-                tcull = __uint_as_float((uint32_t)(key >> 32)) * 1.0001f + 1e-3f;
+                bestkey = key; best_first = first;
+                tcull = __builtin_fmaf(__uint_as_float(tm), 1.0001f, 1e-3f);   // a bound only: may be fused
             }
         }
         // pop
@@ -202,7 +196,11 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
         sp--;
         cur = (SPILL && sp >= stack_lds) ? spill[(size_t)(sp - stack_lds) * spill_stride + gray] : my[sp * kRaysPerWave];
     }
-    best.t = __uint_as_float((uint32_t)(bestkey >> 32)); best.face = (uint32_t)bestkey;
+    Hit best;
+    best.t = __uint_as_float((uint32_t)(bestkey >> 32));
+    const bool hit = (uint32_t)(bestkey >> 32) < 0x7F800000u;
+    best.face = hit ? ((uint32_t)bestkey >> 2) : 0xFFFFFFFFu;
+    best.tri = hit ? best_first + ((uint32_t)bestkey & 3u) : 0xFFFFFFFFu;
     return best;
 }
 
