@@ -357,9 +357,15 @@ __device__ inline void fresnel_split(V3 n, const V3 d, const double energy, cons
     } else if (s > M_PI - eps) {
         rs = 1.0; rp = 1.0;
     } else {
+        // rs = -sin(df) / sin(s), rp = tan(df) / tan(s)  (radar_algorithms.h:116-121).  One sincos per angle
+        // (one argument reduction) instead of sin + tan; tan = sin / cos is within an ulp of libm's tan --
+        // the same freedom the GPU's libm already has against the host's
         const double df = incidence_angle - refraction_angle;
-        rs = -sin(df) / sin(s);
-        rp = tan(df) / tan(s);
+        double sd, cd, ss, cs;
+        sincos(df, &sd, &cd);
+        sincos(s, &ss, &cs);
+        rs = -sd / ss;
+        rp = (sd / cd) / (ss / cs);
     }
     const double Rs = rs * rs, Rp = rp * rp;
     const double Reff = polarization * Rs + (1.0 - polarization) * Rp;
