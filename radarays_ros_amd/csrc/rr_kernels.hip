@@ -878,8 +878,25 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         __syncthreads();
     }
 
+    // noise amplitude of one bin as a function of its signal (RadarCPU.cpp:497-512)
+    const float signal_max = max_val;
+    const float signal_amp = signal_max - 0.0f;
+    const float noise_at_0 = (float)((double)signal_amp * P.noise_at_0);
+    const float noise_at_1 = (float)((double)signal_amp * P.noise_at_1);
+    auto noise_amp_of = [&](float signal) -> float {
+        const float signal_ = (float)(1.0 - (double)((signal - 0.0f) / signal_amp));
+        // std::pow(signal_, 4.0) (RadarCPU.cpp:509): two exact-order squarings in f64 differ from a
+        // correctly rounded pow by < 1.5 ulp(f64), invisible after the narrowing to f32
+        const double sg2 = (double)signal_ * (double)signal_;
+        const float signal__ = (float)(sg2 * sg2);
+        return (float)((double)(signal__ * noise_at_0) + (1.0 - (double)signal__) * (double)noise_at_1);
+    };
+    // most bins hold no echo: their amplitude is the SAME expression evaluated at signal = 0 * energy_max,
+    // computed once per column; a wave whose 64 bins are all empty takes it instead of the division chain
+    const float amp_empty = P.ambient_noise ? noise_amp_of(0.0f * P.energy_max_f) : 0.0f;
     for (int i = tid; i < n_cells; i += kColThreads) {
-        float v = lds_col[i] * P.energy_max_f;   // :453
+        const float raw = lds_col[i];
+        float v = raw * P.energy_max_f;   // :453
         if (P.ambient_noise) {   // :459-528
             const float signal = v;
             double p = 0.0;
@@ -891,16 +908,8 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 const double p2 = perlin_col(pc2, random_begin + (double)i * 0.2);
                 p = 0.9 * p1 + 0.1 * p2;
             }
-            const float signal_max = max_val;
-            const float signal_amp = signal_max - 0.0f;
-            const float signal_ = (float)(1.0 - (double)((signal - 0.0f) / signal_amp));
-            const float noise_at_0 = (float)((double)signal_amp * P.noise_at_0);
-            const float noise_at_1 = (float)((double)signal_amp * P.noise_at_1);
-            // std::pow(signal_, 4.0) (RadarCPU.cpp:509): two exact-order squarings in f64 differ from a
-            // correctly rounded pow by < 1.5 ulp(f64), invisible after the narrowing to f32
-            const double sg2 = (double)signal_ * (double)signal_;
-            const float signal__ = (float)(sg2 * sg2);
-            const float noise_amp = (float)((double)(signal__ * noise_at_0) + (1.0 - (double)signal__) * (double)noise_at_1);
+            // (raw != 0 is also true for NaN: such bins take the general expression)
+            const float noise_amp = (__ballot(raw != 0.0f) == 0ull) ? amp_empty : noise_amp_of(signal);
             const float noise_energy_max = (float)((double)signal_max * P.noise_e_max);
             const float noise_energy_min = (float)((double)signal_max * P.noise_e_min);
             float y_noise = (float)((double)noise_amp * p);
