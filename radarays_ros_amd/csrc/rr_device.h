@@ -129,4 +129,6 @@ struct Params {
     int spill_stride, stack_lds, spill_depth;
 };
 
+static_assert(sizeof(Params) <= 4096, "Params is passed by value: HIP kernel arguments are limited to 4 KB");
+
 }  // namespace rr
