@@ -107,7 +107,7 @@ struct rr_ctx {
     int smear_mode = 0;
 
     DevBuf<float4> d_qas, d_beams, d_materials;
-    DevBuf<uint32_t> d_beam_order;
+    DevBuf<uint32_t> d_beam_order, d_beam_order2;
     DevBuf<int32_t> d_objmat;
     DevBuf<float> d_smear, d_noise, d_motion, d_decay;
     DevBuf<uint8_t> d_param_imgs;   // rr_simulate_material_sets: images before the D2H copy
@@ -230,12 +230,25 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, c->d_beams.ensure(nb));
     if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
     {
-        // trace order of pass 0: Morton order of the direction's (y, z) so that a quad /
-        // wave holds neighbouring rays of the cone (RR_NO_BEAM_SORT=1 disables it: A/B experiments)
-        std::vector<uint32_t> order(nb);
-        for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
-        const bool no_sort = getenv("RR_NO_BEAM_SORT") && atoi(getenv("RR_NO_BEAM_SORT")) != 0;
-        if (nb > 1 && !no_sort) {
+        // trace orders (results are always stored under the reference index, so they only change speed):
+        //   pass 0     : rows of 16 rays (= one wave) of nearly equal ELEVATION, sorted by yaw inside the row --
+        //                rays of one elevation travel about equally far, and a wave lasts as long as its
+        //                slowest ray (config 2: k_trace 128 -> 115 us against a Morton order)
+        //   pass 1 ... : inherited through torder from a second order of the beam samples, yaw-major rows
+        //                (the reflected fan of a yaw slice stays together)
+        // RR_BEAM_SORT / RR_BEAM_SORT2 = 1 Morton, 2 elevation-major, 3 yaw-major, 4/5 = 2/3 with rows of 32
+        auto make_order = [&](int mode, std::vector<uint32_t>& order) {
+            order.resize(nb);
+            for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
+            if (nb <= 1) return;
+            if (mode >= 2 && mode <= 5) {
+                const int major = (mode == 2 || mode == 4) ? 2 : 1, minor = 3 - major;
+                const size_t row = mode >= 4 ? 32 : 16;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + major] < c->beams[3 * b + major]; });
+                for (size_t i = 0; i < nb; i += row)
+                    std::stable_sort(order.begin() + i, order.begin() + std::min(nb, i + row), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + minor] < c->beams[3 * b + minor]; });
+                return;
+            }
             float lo[2] = { 1e30f, 1e30f }, hi[2] = { -1e30f, -1e30f };
             for (size_t i = 0; i < nb; i++) for (int k = 0; k < 2; k++) {
                 lo[k] = std::min(lo[k], c->beams[3 * i + 1 + k]); hi[k] = std::max(hi[k], c->beams[3 * i + 1 + k]);
@@ -253,7 +266,12 @@ int upload_tables(rr_ctx* c)
                 code[i] = m;
             }
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
-        }
+        };
+        std::vector<uint32_t> order, order2;
+        make_order(getenv("RR_BEAM_SORT") ? atoi(getenv("RR_BEAM_SORT")) : 2, order);
+        make_order(getenv("RR_BEAM_SORT2") ? atoi(getenv("RR_BEAM_SORT2")) : 3, order2);
+        RR_HIP(c, c->d_beam_order2.ensure(nb));
+        if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order2.p, order2.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
         RR_HIP(c, c->d_beam_order.ensure(nb));
         if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order.p, order.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
@@ -363,7 +381,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     const rr_config& g = c->cfg;
     std::memset(&P, 0, sizeof(P));
     P.nodes = c->d_nodes.p; P.tris = c->d_tris.p;
-    P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.materials = c->d_materials.p;
+    P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.beam_order2 = c->d_beam_order2.p; P.materials = c->d_materials.p;
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
     P.decay = c->d_decay.p;
@@ -535,7 +553,7 @@ void rr_destroy(rr_ctx* c)
     (void)hipDeviceSynchronize();   // frames may still be in flight on the lanes' or the caller's streams
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
-    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_motion.release();
+    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_beam_order2.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }

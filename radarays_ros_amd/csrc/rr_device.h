@@ -83,7 +83,8 @@ struct Params {
     // per-config tables
     const float4* q_as;          // [n_angles] Tas.R (RadarCPU.cpp:202)
     const float4* beams;         // [n_beam] xyz
-    const uint32_t* beam_order;  // [n_beam] trace slot -> beam index (spatially sorted: coherent quads/waves)
+    const uint32_t* beam_order;  // [n_beam] trace slot -> beam index of pass 0 (rows of equal elevation: equally long rays share a wave)
+    const uint32_t* beam_order2; // [n_beam] the order the LATER passes inherit (yaw-major rows)
     const float4* materials;     // [n_materials] velocity, ambient, diffuse, specular
     const int32_t* object_materials;
     const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)

@@ -216,20 +216,31 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     // pose algebra four times and every wave would issue it for just 16 rays)
     __shared__ float s_ray[12][kRaysPerBlock];
     __shared__ int s_j[kRaysPerBlock];
-    const int seg = blockIdx.y;
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int cur = pass & 1;
-    const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
+    // pass 0: the rays of ALL segments form one sequence (grid.y == 1), so every wave is full (200 rays per
+    // azimuth would otherwise leave a 13th wave with 8 rays); odd segments run through the beam order
+    // backwards, so the wave that straddles two segments holds rays of one end of the elevation range
+    const int n_first = FIRST ? ((P.share_first ? P.n_loc : P.n_seg) * P.n_beam) : 0;
+    const int count = FIRST ? n_first : (int)P.count[cur][blockIdx.y];
     if ((int)(blockIdx.x * kRaysPerBlock) >= count) return;
+    __shared__ int s_seg[kRaysPerBlock];
     if (threadIdx.x < kRaysPerBlock) {
         const int rr = threadIdx.x;
-        const int k = blockIdx.x * kRaysPerBlock + rr;     // trace slot
-        // pass 0 is traced in a spatially sorted order of the beam samples; results are
+        int k = blockIdx.x * kRaysPerBlock + rr;           // trace slot
+        int seg = blockIdx.y;
+        const bool live = k < count;
+        if (FIRST) {
+            seg = k / P.n_beam; k -= seg * P.n_beam;
+            if (seg & 1) k = P.n_beam - 1 - k;
+            if (!live) seg = 0;
+        }
+        // pass 0 is traced in a sorted order of the beam samples (rows of equal elevation); results are
         // stored under the wave's own index j, so the reference order is untouched
         int j = -1;
         V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
-        if (k < count) {
+        if (live) {
             j = FIRST ? (int)P.beam_order[k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
             if (FIRST) {
                 const float4 b = P.beams[j];
@@ -249,10 +260,11 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         s_ray[3][rr] = R.d.x; s_ray[4][rr] = R.d.y; s_ray[5][rr] = R.d.z;
         s_ray[6][rr] = R.idx; s_ray[7][rr] = R.idy; s_ray[8][rr] = R.idz;
         s_ray[9][rr] = R.oox; s_ray[10][rr] = R.ooy; s_ray[11][rr] = R.ooz;
-        s_j[rr] = j;
+        s_j[rr] = j; s_seg[rr] = seg;
     }
     __syncthreads();
     const int j = s_j[r];
+    const int seg = s_seg[r];
     const bool active = j >= 0;
 
     unsigned nn = 0, nt = 0;
@@ -583,7 +595,7 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
                 const int k = b + threadIdx.x;
                 int c = 0; uint32_t rp = 0xFFFFFFFFu;
                 if (k < count) {
-                    const uint32_t j = FIRST ? P.beam_order[k] : P.torder[cur][(size_t)seg * P.cap + k];
+                    const uint32_t j = FIRST ? P.beam_order2[k] : P.torder[cur][(size_t)seg * P.cap + k];
                     const size_t sl = base2 + 2 * (size_t)j + type;
                     if (P.cflag[sl] & 1) { rp = P.refpos[sl]; c = rp != 0xFFFFFFFFu; }
                 }
@@ -1008,9 +1020,11 @@ __global__ __launch_bounds__(256) void k_assemble_u8x4(const uint8_t* __restrict
 // ---------------------------------------------------------------------------
 void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const int cap_p = pass == 0 ? P.n_beam : P.cap;
     const int n_seg = (pass == 0 && P.share_first) ? P.n_loc : P.n_seg;
-    dim3 grid((cap_p + kRaysPerBlock - 1) / kRaysPerBlock, n_seg), block(kTraceThreads);
+    // pass 0: one flat sequence of n_seg x n_beam rays; later passes: a row of blocks per segment
+    dim3 grid = pass == 0 ? dim3((unsigned)(((size_t)n_seg * P.n_beam + kRaysPerBlock - 1) / kRaysPerBlock))
+                          : dim3((P.cap + kRaysPerBlock - 1) / kRaysPerBlock, n_seg);
+    dim3 block(kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
