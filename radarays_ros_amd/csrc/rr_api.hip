@@ -231,9 +231,9 @@ int upload_tables(rr_ctx* c)
     if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
     {
         // trace orders (results are always stored under the reference index, so they only change speed):
-        //   pass 0     : rows of 16 rays (= one wave) of nearly equal ELEVATION, sorted by yaw inside the row --
-        //                rays of one elevation travel about equally far, and a wave lasts as long as its
-        //                slowest ray (config 2: k_trace 128 -> 115 us against a Morton order)
+        //   pass 0     : k_trace walks the rays SAMPLE-major (one beam sample of 16 neighbouring azimuths per
+        //                wave); this order only decides which samples are neighbours in the grid: rows of
+        //                nearly equal elevation, sorted by yaw inside a row
         //   pass 1 ... : inherited through torder from a second order of the beam samples, yaw-major rows
         //                (the reflected fan of a yaw slice stays together)
         // RR_BEAM_SORT / RR_BEAM_SORT2 = 1 Morton, 2 elevation-major, 3 yaw-major, 4/5 = 2/3 with rows of 32

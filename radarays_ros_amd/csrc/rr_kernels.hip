@@ -219,9 +219,11 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int cur = pass & 1;
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
-    // pass 0: the rays of ALL segments form one sequence (grid.y == 1), so every wave is full (200 rays per
-    // azimuth would otherwise leave a 13th wave with 8 rays); odd segments run through the beam order
-    // backwards, so the wave that straddles two segments holds rays of one end of the elevation range
+    // pass 0: the rays of ALL segments form one sequence (grid.y == 1), SAMPLE-major: a wave holds the same
+    // beam sample of 16 neighbouring azimuths -- 16 rays of identical elevation, 0.9 degrees apart, that walk
+    // almost the same nodes in lockstep (few iterations that pay both the node and the leaf path, no slow
+    // ray to wait for): k_trace 128 us (Morton order inside one azimuth) -> 80 us per 640k rays at config 2.
+    // Every wave is full, too (200 rays per azimuth would otherwise leave a 13th wave with 8 rays)
     const int n_first = FIRST ? ((P.share_first ? P.n_loc : P.n_seg) * P.n_beam) : 0;
     const int count = FIRST ? n_first : (int)P.count[cur][blockIdx.y];
     if ((int)(blockIdx.x * kRaysPerBlock) >= count) return;
@@ -232,9 +234,9 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         int seg = blockIdx.y;
         const bool live = k < count;
         if (FIRST) {
-            seg = k / P.n_beam; k -= seg * P.n_beam;
-            if (seg & 1) k = P.n_beam - 1 - k;
-            if (!live) seg = 0;
+            const int ns = count / P.n_beam;
+            const int kk = k / ns; seg = k - kk * ns; k = kk;
+            if (!live) { seg = 0; k = 0; }
         }
         // pass 0 is traced in a sorted order of the beam samples (rows of equal elevation); results are
         // stored under the wave's own index j, so the reference order is untouched
