@@ -744,6 +744,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     __shared__ unsigned char s_perm[256];
     __shared__ double2 s_grad[256];
     __shared__ int2 s_list[kColWaves][64];         // per wave: overlapping signals of one 64-signal batch
+    __shared__ int s_wcnt[kColWaves];
 
     const int seg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -770,27 +771,40 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     int n_valid_last = 0, n_hit_last = 0;
     float rmax = 0.0f;          // running maximum of the bins this lane accumulates (max_val, RadarCPU.cpp:404)
     for (int c0 = 0; c0 < S; c0 += kSigChunk) {
-        const int n = min(kSigChunk, S - c0);
+        const int n_in = min(kSigChunk, S - c0);
         if (tid < 2) s_tiles[tid] = 0ull;
-        __syncthreads();
-        for (int i = tid; i < n; i += kColThreads) {
+        // stage the chunk, keeping only the signals that land in the image (RadarCPU.cpp:414), IN ORDER:
+        // ballot rank inside the wave + the counts of the waves before it (the per-wave slots of the last
+        // pass are half empty -- no multipath echo -- so the replay scans half as many entries)
+        int n = 0;
+        for (int r0 = 0; r0 < n_in; r0 += kColThreads) {
+            const int i = r0 + tid;
             const int v = c0 + i;
-            SigRec r;
-            if (v < n_list) r = P.sig[(size_t)seg * P.sigcap + v];
-            else {
-                r = P.sigtmp[base2 + (v - n_list)];
-                n_valid_last += r.cell >= 0;
-                n_hit_last += (P.cflag[base2 + (v - n_list)] >> 2) & 1;
+            SigRec r; r.cell = -1; r.strength = 0.0f;
+            if (i < n_in) {
+                if (v < n_list) r = P.sig[(size_t)seg * P.sigcap + v];
+                else {
+                    r = P.sigtmp[base2 + (v - n_list)];
+                    n_valid_last += r.cell >= 0;
+                    n_hit_last += (P.cflag[base2 + (v - n_list)] >> 2) & 1;
+                }
             }
-            if (r.cell < 0 || r.cell >= n_cells) r.cell = 0x40000000;   // RadarCPU.cpp:414 / no signal
-            s_sig[i] = r;
-            if (r.cell < n_cells) {
+            const bool keep = r.cell >= 0 && r.cell < n_cells;
+            const unsigned long long km = __ballot(keep);
+            if (lane == 0) s_wcnt[wid] = __builtin_popcountll(km);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < kColWaves; w++) { const int cw = s_wcnt[w]; before += w < wid ? cw : 0; total += cw; }
+            if (keep) {
+                const int pos = n + before + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+                s_sig[pos] = r;
                 int lo = r.cell - mode, hi = r.cell - mode + W - 1;
                 lo = max(lo, 0); hi = min(hi, n_cells - 1);
                 for (int t = lo >> 6; t <= (hi >> 6); t++) atomicOr(&s_tiles[t >> 6], 1ull << (t & 63));
             }
+            n += total;
+            __syncthreads();
         }
-        __syncthreads();
         for (int t = wid; t < n_tiles; t += kColWaves) {
             if (!((s_tiles[t >> 6] >> (t & 63)) & 1ull)) continue;
             const int g = t * 64 + lane;
