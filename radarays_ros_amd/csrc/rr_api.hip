@@ -124,6 +124,7 @@ struct rr_ctx {
     int stream_lanes = 3;          // lanes whose own stream rr_simulate_device uses
 
     bool stats_mode = false;
+    int pass0_az = 16;
     int timing = 0;   // 0 off, 1 every kernel, 2 k_trace only
     std::map<std::string, KernelTimer> timers;
 };
@@ -231,45 +232,23 @@ int upload_tables(rr_ctx* c)
     if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
     {
         // trace orders (results are always stored under the reference index, so they only change speed):
-        //   pass 0     : k_trace walks the rays SAMPLE-major (one beam sample of 16 neighbouring azimuths per
-        //                wave); this order only decides which samples are neighbours in the grid: rows of
-        //                nearly equal elevation, sorted by yaw inside a row
+        //   pass 0     : k_trace tiles (beam sample, azimuth) into waves itself (see there); this order
+        //                decides which samples share a tile / are neighbours in the launch: rows of nearly
+        //                equal elevation, sorted by yaw inside a row
         //   pass 1 ... : inherited through torder from a second order of the beam samples, yaw-major rows
-        //                (the reflected fan of a yaw slice stays together)
-        // RR_BEAM_SORT / RR_BEAM_SORT2 = 1 Morton, 2 elevation-major, 3 yaw-major, 4/5 = 2/3 with rows of 32
-        auto make_order = [&](int mode, std::vector<uint32_t>& order) {
+        //                (the reflected fan of a yaw slice stays together; measured against elevation-major
+        //                and Morton orders)
+        auto make_order = [&](int major, std::vector<uint32_t>& order) {   // major: 2 = elevation (z), 1 = yaw (y)
             order.resize(nb);
             for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
-            if (nb <= 1) return;
-            if (mode >= 2 && mode <= 5) {
-                const int major = (mode == 2 || mode == 4) ? 2 : 1, minor = 3 - major;
-                const size_t row = mode >= 4 ? 32 : 16;
-                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + major] < c->beams[3 * b + major]; });
-                for (size_t i = 0; i < nb; i += row)
-                    std::stable_sort(order.begin() + i, order.begin() + std::min(nb, i + row), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + minor] < c->beams[3 * b + minor]; });
-                return;
-            }
-            float lo[2] = { 1e30f, 1e30f }, hi[2] = { -1e30f, -1e30f };
-            for (size_t i = 0; i < nb; i++) for (int k = 0; k < 2; k++) {
-                lo[k] = std::min(lo[k], c->beams[3 * i + 1 + k]); hi[k] = std::max(hi[k], c->beams[3 * i + 1 + k]);
-            }
-            std::vector<uint32_t> code(nb);
-            for (size_t i = 0; i < nb; i++) {
-                uint32_t m = 0;
-                uint32_t u[2];
-                for (int k = 0; k < 2; k++) {
-                    const float e = hi[k] - lo[k];
-                    const float t = e > 0.f ? (c->beams[3 * i + 1 + k] - lo[k]) / e : 0.f;
-                    u[k] = (uint32_t)std::min(65535.0f, std::max(0.0f, t * 65535.0f));
-                }
-                for (int b = 0; b < 16; b++) m |= ((u[0] >> b) & 1u) << (2 * b) | ((u[1] >> b) & 1u) << (2 * b + 1);
-                code[i] = m;
-            }
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+            const int minor = 3 - major;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + major] < c->beams[3 * b + major]; });
+            for (size_t i = 0; i < nb; i += 16)
+                std::stable_sort(order.begin() + i, order.begin() + std::min(nb, i + 16), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + minor] < c->beams[3 * b + minor]; });
         };
         std::vector<uint32_t> order, order2;
-        make_order(getenv("RR_BEAM_SORT") ? atoi(getenv("RR_BEAM_SORT")) : 2, order);
-        make_order(getenv("RR_BEAM_SORT2") ? atoi(getenv("RR_BEAM_SORT2")) : 3, order2);
+        make_order(2, order);
+        make_order(1, order2);
         RR_HIP(c, c->d_beam_order2.ensure(nb));
         if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order2.p, order2.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
         RR_HIP(c, c->d_beam_order.ensure(nb));
@@ -414,6 +393,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.noise_e_loss = g.ambient_noise_energy_loss;
     P.spill_stride = L.spill_stride; P.stack_lds = L.stack_lds;
     P.spill_depth = std::max(0, (int)c->stack_need - L.stack_lds);
+    P.pass0_az = c->pass0_az;
 }
 
 struct TimedScope {
@@ -535,6 +515,7 @@ rr_ctx* rr_create(int device)
     n_lanes = std::max(1, std::min(n_lanes, 8));
     c->stream_lanes = getenv("RR_STREAM_LANES") ? std::max(1, std::min(atoi(getenv("RR_STREAM_LANES")), n_lanes))
                                                 : std::min(3, n_lanes);
+    if (getenv("RR_PASS0_AZ")) { const int a = atoi(getenv("RR_PASS0_AZ")); if (a == 1 || a == 2 || a == 4 || a == 8 || a == 16) c->pass0_az = a; }
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||

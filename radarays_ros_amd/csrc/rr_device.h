@@ -128,6 +128,7 @@ struct Params {
     double signal_max;
     double noise_at_0, noise_at_1, noise_e_max, noise_e_min, noise_e_loss;
     int spill_stride, stack_lds, spill_depth;
+    int pass0_az;                // pass 0: neighbouring segments per wave (power of two <= 16); 16 / pass0_az samples each
 };
 
 static_assert(sizeof(Params) <= 4096, "Params is passed by value: HIP kernel arguments are limited to 4 KB");

@@ -219,23 +219,30 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int cur = pass & 1;
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
-    // pass 0: the rays of ALL segments form one sequence (grid.y == 1), SAMPLE-major: a wave holds the same
-    // beam sample of 16 neighbouring azimuths -- 16 rays of identical elevation, 0.9 degrees apart, that walk
-    // almost the same nodes in lockstep (few iterations that pay both the node and the leaf path, no slow
-    // ray to wait for): k_trace 128 us (Morton order inside one azimuth) -> 80 us per 640k rays at config 2.
+    // pass 0: the rays of ALL segments of the launch are tiled into waves of (16 / A) beam samples x A
+    // neighbouring azimuths (A = pass0_az = 16: ONE sample in 16 azimuths, i.e. 16 rays of identical
+    // elevation, 0.9 degrees apart, that walk almost the same nodes in lockstep -- few iterations pay both
+    // the node and the leaf path, no slow ray to wait for), and the tiles are launched sample-block-major,
+    // so the waves that run at the same time are neighbours in azimuth: k_trace 128 us (round 1: Morton
+    // order of the samples inside one azimuth, azimuth after azimuth) -> 80 us per 640k rays at config 2.
     // Every wave is full, too (200 rays per azimuth would otherwise leave a 13th wave with 8 rays)
-    const int n_first = FIRST ? ((P.share_first ? P.n_loc : P.n_seg) * P.n_beam) : 0;
-    const int count = FIRST ? n_first : (int)P.count[cur][blockIdx.y];
-    if ((int)(blockIdx.x * kRaysPerBlock) >= count) return;
+    const int count = FIRST ? 0 : (int)P.count[cur][blockIdx.y];
+    if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
     __shared__ int s_seg[kRaysPerBlock];
     if (threadIdx.x < kRaysPerBlock) {
         const int rr = threadIdx.x;
         int k = blockIdx.x * kRaysPerBlock + rr;           // trace slot
         int seg = blockIdx.y;
-        const bool live = k < count;
+        bool live = k < count;
         if (FIRST) {
-            const int ns = count / P.n_beam;
-            const int kk = k / ns; seg = k - kk * ns; k = kk;
+            // wave w = tile (sample block sb, azimuth block ab) of (16 / A) samples x A neighbouring segments
+            const int ns = P.share_first ? P.n_loc : P.n_seg;
+            const int A = P.pass0_az, lgA = 31 - __builtin_clz(A), Sw = kRaysPerWave >> lgA;
+            const int n_ab = (ns + A - 1) >> lgA;
+            const int w = blockIdx.x * (kRaysPerBlock / kRaysPerWave) + (rr >> 4), r16 = rr & 15;
+            const int sb = w / n_ab, ab = w - sb * n_ab;
+            k = sb * Sw + (r16 >> lgA); seg = (ab << lgA) + (r16 & (A - 1));
+            live = k < P.n_beam && seg < ns;
             if (!live) { seg = 0; k = 0; }
         }
         // pass 0 is traced in a sorted order of the beam samples (rows of equal elevation); results are
@@ -1038,7 +1045,9 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
 {
     const int n_seg = (pass == 0 && P.share_first) ? P.n_loc : P.n_seg;
     // pass 0: one flat sequence of n_seg x n_beam rays; later passes: a row of blocks per segment
-    dim3 grid = pass == 0 ? dim3((unsigned)(((size_t)n_seg * P.n_beam + kRaysPerBlock - 1) / kRaysPerBlock))
+    const int A0 = P.pass0_az, Sw0 = kRaysPerWave / A0;
+    const size_t waves0 = (size_t)((n_seg + A0 - 1) / A0) * (size_t)((P.n_beam + Sw0 - 1) / Sw0);
+    dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + 1) / 2))
                           : dim3((P.cap + kRaysPerBlock - 1) / kRaysPerBlock, n_seg);
     dim3 block(kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
