@@ -53,8 +53,9 @@ WORKLOADS = {
     "config3_1M_400x200_4pass": (3, 4, 200),
     "config4_10M_400x1000_4pass": (4, 4, 1000),
     "target_10M_400x200_4pass": (4, 4, 200),
-    # configs[4] minus its BRDF: per-triangle materials (8), 8 passes, 10M triangles -- the Cook-Torrance
-    # model lives on the reference's dev/flex branch, not in the checkout; run with --frames-per-rank 1
+    # configs[4]: per-triangle materials (8), 8 passes, 10M triangles, Cook-Torrance lobe (rr_config.brdf_model = 1:
+    # the build's own GGX / Smith specification -- the reference's model lives on its dev/flex branch, not in the
+    # checkout, so this one config is parity-unpinned); run with --frames-per-rank 1
     "config5_10M_400x1000_8pass_pertri": (5, 8, 1000),
 }
 
@@ -110,7 +111,7 @@ def main():
     ctx = native.Context(local_rank)
     ctx.set_mesh(scene["verts"], scene["faces"], scene["face_object_id"])
     ctx.set_materials(mats, scene["object_materials"], 0)
-    ctx.set_config(cfg, params.N_ANGLES)
+    ctx.set_config(cfg, params.N_ANGLES, brdf_model=1 if scene_id == 5 else 0)
     ctx.set_beam_samples(beams)
     ctx.set_noise_offsets(noise)
     n_tris = len(scene["faces"])
@@ -236,7 +237,8 @@ def main():
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(scene, cfg, mats, beams, noise, poses, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(scene, cfg, mats, beams, noise, poses, args.cpu_seconds,
+                                           brdf_model=1 if scene_id == 5 else 0)
 
     shard.close()
     ctx.close()
@@ -246,7 +248,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s):
+def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
     """The oracle (kind "port") on the host cores of this box, bounded sample."""
     from oracle import oracle as O
     O.build()
@@ -256,7 +258,7 @@ def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s):
 
     def frame(k, nt):
         _, _, st = O.simulate(sc, m, scene["object_materials"], cfg, beams, poses[k % len(poses)],
-                              noise_rnd=noise, want_f32=False, n_threads=nt)
+                              noise_rnd=noise, want_f32=False, n_threads=nt, brdf_model=brdf_model)
         return st["seconds"]
 
     # the reference parallelises azimuths with OpenMP (RadarCPU.cpp:155); pick the thread

@@ -55,6 +55,11 @@ typedef struct rr_config {
     int32_t record_multi_path;       /* :82 */
     int32_t max_waves_per_azimuth;   /* build's own: capacity of the per-azimuth wave queue per pass;
                                         0 = n_samples * 2^(n_reflections-1) clamped to 65536 */
+    int32_t brdf_model;              /* build's own: 0 = the checkout's A + B cos^C (radar_algorithms.h:168-187);
+                                        1 = Cook-Torrance lobe, A + B * D_GGX * G_Smith normalised to 1 at normal
+                                        incidence, alpha^2 = 2 / (C + 2) (BASELINE.json configs[4]; the reference's own
+                                        version lives on its dev/flex branch, outside the checkout: PARITY UNPINNED) */
+    int32_t reserved_;
     double  resolution;              /* :15  m per range bin */
     double  energy_max;              /* :32 */
     double  signal_max;              /* :33 */

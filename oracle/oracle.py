@@ -42,7 +42,7 @@ class OrcConfig(C.Structure):
         ("ambient_noise_energy_max", C.c_double), ("ambient_noise_energy_min", C.c_double),
         ("ambient_noise_energy_loss", C.c_double), ("multipath_threshold", C.c_double),
         ("wave_energy_threshold", C.c_float), ("theta_min", C.c_float),
-        ("theta_inc", C.c_float), ("pad_", C.c_float),
+        ("theta_inc", C.c_float), ("brdf_model", C.c_int32),
     ]
 
 
@@ -88,6 +88,8 @@ def lib():
     L.orc_fresnel.argtypes = [fp, fp, C.c_double, C.c_double, C.c_double, C.c_double,
                               fp, C.POINTER(C.c_double), fp, C.POINTER(C.c_double)]
     L.orc_back_reflection_shader.restype = C.c_float
+    L.orc_ct_lobe.restype = C.c_float
+    L.orc_ct_lobe.argtypes = [C.c_float, C.c_float]
     L.orc_back_reflection_shader.argtypes = [C.c_float] * 5
     L.orc_incidence_angle.restype = C.c_double
     L.orc_incidence_angle.argtypes = [fp, fp]
@@ -135,6 +137,10 @@ def fresnel(normal, direction, energy=1.0, polarization=0.5, v1=0.3, v2=0.0):
     return np.array(rd[:], np.float32), re.value, np.array(td[:], np.float32), te.value
 
 
+def ct_lobe(angle, specular_exp):
+    return float(lib().orc_ct_lobe(angle, specular_exp))
+
+
 def back_reflection_shader(angle, energy, a, b, c):
     return float(lib().orc_back_reflection_shader(angle, energy, a, b, c))
 
@@ -175,7 +181,7 @@ def saturate_u8(x):
     return int(lib().orc_saturate_u8(x))
 
 
-def make_config(cfg, n_angles=400, material_id_air=0, wave_energy_threshold=0.001):
+def make_config(cfg, n_angles=400, material_id_air=0, wave_energy_threshold=0.001, brdf_model=0):
     """RadarModelConfig-like object -> OrcConfig (Radar.cpp:22-32 constants)."""
     c = OrcConfig()
     c.n_cells = int(cfg.n_cells)
@@ -199,6 +205,7 @@ def make_config(cfg, n_angles=400, material_id_air=0, wave_energy_threshold=0.00
     c.wave_energy_threshold = float(np.float32(wave_energy_threshold))
     c.theta_min = 0.0
     c.theta_inc = float(np.float32(-(2.0 * np.pi) / n_angles))
+    c.brdf_model = int(brdf_model)
     return c
 
 
@@ -231,11 +238,11 @@ class Scene:
 
 def simulate(scene, materials, object_materials, cfg, beam_dirs, pose, noise_rnd=None,
              az_begin=0, az_end=None, n_angles=400, material_id_air=0, want_f32=True,
-             n_threads=0):
+             n_threads=0, brdf_model=0):
     """RadarCPU::simulate on the oracle. materials: [(velocity, ambient, diffuse, specular)].
     Returns (u8 [n_cells][n_angles], f32 or None, stats dict)."""
     L = lib()
-    oc = make_config(cfg, n_angles, material_id_air)
+    oc = make_config(cfg, n_angles, material_id_air, brdf_model=brdf_model)
     if az_end is None:
         az_end = n_angles
     mats = (OrcMaterial * len(materials))(*[OrcMaterial(*[float(x) for x in m]) for m in materials])

@@ -260,6 +260,33 @@ float orc_back_reflection_shader(float incidence_angle, float energy,
     return I_total * energy;
 }
 
+/* NOT in the reference checkout.  BASELINE.json configs[4] names the Cook-Torrance reflection model of the
+ * reference's dev/flex branch (README.md:83-85), which is not part of /root/reference: there is no code to
+ * restate and no vector to pin, so this is the BUILD'S OWN specification (PARITY UNPINNED), checked by
+ * self-consistency tests only.  The cos^C lobe of back_reflection_shader is replaced by the microfacet
+ * backscatter lobe D_GGX * G_Smith, normalised to 1 at normal incidence; alpha^2 = 2 / (C + 2).  f32. */
+float orc_ct_lobe(float angle, float specular_exp)
+{
+    float c = cosf(angle), sn = sinf(angle);
+    if (!(c > 0.0f)) return 0.0f;
+    float a2 = 2.0f / (specular_exp + 2.0f);
+    a2 = fminf(fmaxf(a2, 1e-4f), 1.0f);
+    float cc = c * c;
+    float d = a2 * cc + sn * sn;              /* = cc (a2 - 1) + 1 without the cancellation near normal incidence */
+    float D = a2 / (d * d);
+    float g1 = (2.0f * c) / (c + sqrtf(a2 + (1.0f - a2) * cc));
+    return a2 * D * (g1 * g1);
+}
+
+float orc_back_reflection_shader_model(float incidence_angle, float energy,
+                                       float diffuse, float specular_fac, float specular_exp, int model)
+{
+    if (model != 1) return orc_back_reflection_shader(incidence_angle, energy, diffuse, specular_fac, specular_exp);
+    float I_specular = orc_ct_lobe(incidence_angle, specular_exp);
+    float I_total = diffuse * 1.0f + specular_fac * I_specular;
+    return I_total * energy;
+}
+
 /* radar_algorithms.h:267-281 */
 static void normalize_inplace(float* data, int n)
 {
@@ -836,9 +863,9 @@ static int simulate_impl(const orc_scene* scene,
                     {
                         const orc_material material = materials[refraction.material_id];
                         double incidence_angle = incidence_angle_of(surface_normal, incidence.dir);   /* :308 */
-                        double return_energy_path = (double)orc_back_reflection_shader(   /* :310-316 */
+                        double return_energy_path = (double)orc_back_reflection_shader_model(   /* :310-316 */
                             (float)incidence_angle, (float)reflection.energy,
-                            material.ambient, material.diffuse, material.specular);
+                            material.ambient, material.diffuse, material.specular, cfg->brdf_model);
 
                         if (pass_id == 0 || cfg->record_multi_reflection) {   /* :319 */
                             float time_back = (float)(incidence.time * 2.0);
@@ -853,9 +880,9 @@ static int simulate_impl(const orc_scene* scene,
                             double sensor_view_scalar = (double)v3_dot(wave.dir, dir_sensor_to_hit);
                             double ang = (double)acosf(v3_dot(v3_neg(reflection.dir), dir_sensor_to_hit));   /* angle_between, radar_algorithms.h:17-23 */
                             if (sensor_view_scalar > cfg->multipath_threshold) {   /* :344-345 */
-                                double return_energy_air = (double)orc_back_reflection_shader(
+                                double return_energy_air = (double)orc_back_reflection_shader_model(
                                     (float)ang, (float)reflection.energy,
-                                    material.ambient, material.diffuse, material.specular);
+                                    material.ambient, material.diffuse, material.specular, cfg->brdf_model);
                                 sv_push(&signals, incidence.time + time_to_sensor, return_energy_air);
                             }
                         }

@@ -72,7 +72,7 @@ typedef struct {
     float   wave_energy_threshold;   /* Radar.cpp:24 (0.001) */
     float   theta_min;               /* Radar.cpp:28 */
     float   theta_inc;               /* Radar.cpp:27  -(2 pi)/400 */
-    float   pad_;
+    int32_t brdf_model;              /* NOT a reference field: 0 = radar_algorithms.h:168-187, 1 = orc_ct_lobe (see there) */
 } orc_config;
 
 typedef struct {
@@ -138,6 +138,9 @@ void orc_fresnel(const float normal[3], const float dir[3],
                  float refl_dir[3], double* refl_energy,
                  float refr_dir[3], double* refr_energy);
 /* radar_algorithms.h:168-187 */
+float orc_ct_lobe(float angle, float specular_exp);
+float orc_back_reflection_shader_model(float incidence_angle, float energy,
+                                       float diffuse, float specular_fac, float specular_exp, int model);
 float orc_back_reflection_shader(float incidence_angle, float energy,
                                  float diffuse, float specular_fac, float specular_exp);
 /* radar_algorithms.h:25-31 */

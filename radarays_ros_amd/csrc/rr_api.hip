@@ -382,6 +382,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.material_id_air = c->material_id_air;
     P.n_passes = g.n_reflections;
     P.record_multi_reflection = g.record_multi_reflection; P.record_multi_path = g.record_multi_path;
+    P.brdf_model = g.brdf_model;
     P.signal_denoising = c->smear.empty() ? 0 : g.signal_denoising;
     P.smear_w = (int)c->smear.size(); P.smear_mode = c->smear_mode;
     P.ambient_noise = g.ambient_noise; P.scroll = g.scroll_image;
@@ -629,6 +630,7 @@ int rr_set_config(rr_ctx* c, const rr_config* cfg)
                 : cfg->signal_denoising == 3 ? cfg->signal_denoising_mb_width : 0;
     if (w < 0 || w > 256) return fail(c, -3, "rr_set_config: smear width must be in [0, 256]");
     if (cfg->ambient_noise < 0 || cfg->ambient_noise > 2) return fail(c, -3, "rr_set_config: ambient_noise must be 0..2");
+    if (cfg->brdf_model < 0 || cfg->brdf_model > 1) return fail(c, -3, "rr_set_config: brdf_model must be 0 (A + B cos^C) or 1 (Cook-Torrance lobe)");
     if (!(cfg->resolution > 0.0)) return fail(c, -3, "rr_set_config: resolution must be > 0");
     // mode = (int)(fraction * width) indexes the weight table (RadarCPU.cpp:48-93): the reference's
     // sliders keep the fraction in [0, 1) (cfg/RadarModel.cfg:47-51); anything else would read outside it.

@@ -121,6 +121,7 @@ struct Params {
     int n_beam, cap, sigcap;
     int n_cells, n_angles, n_materials, n_objects, material_id_air;
     int n_passes, record_multi_reflection, record_multi_path;
+    int brdf_model;              // 0: A + B cos^C (reference); 1: Cook-Torrance lobe (build's own, rr_config.brdf_model)
     int signal_denoising, smear_w, smear_mode, ambient_noise, scroll;
     float thr, range_max;
     double resolution, multipath_threshold;

@@ -395,12 +395,36 @@ __device__ inline void fresnel_split(V3 n, const V3 d, const double energy, cons
     tenergy = Teff * energy;
 }
 
-// radar_algorithms.h:168-187
-__device__ inline float back_reflection_shader(float incidence_angle, float energy,
-                                               float diffuse, float specular_fac, float specular_exp)
+// NOT in the reference checkout (its Cook-Torrance model lives on the dev/flex branch, README.md:83-85):
+// this build's own specification for BASELINE.json configs[4], PARITY UNPINNED.  The cos^C lobe of the
+// shader below is replaced by the microfacet backscatter lobe D_GGX * G_Smith, normalised to 1 at normal
+// incidence (monostatic radar: light, view and half vector coincide, so the Fresnel term is the one already
+// in the reflected energy), with alpha^2 = 2 / (C + 2) (Blinn-Phong exponent -> GGX roughness).  f32, un-fused,
+// the same operation order as the CPU twin the parity tests compare it with.
+__device__ inline float ct_lobe(float angle, float specular_exp)
 {
-    const float IdotR = cosf(incidence_angle);
-    const float I_specular = powf(IdotR, specular_exp);
+    float sn, c;
+    sincosf(angle, &sn, &c);
+    if (!(c > 0.0f)) return 0.0f;
+    float a2 = 2.0f / (specular_exp + 2.0f);
+    a2 = fminf(fmaxf(a2, 1e-4f), 1.0f);
+    const float cc = c * c;
+    const float d = a2 * cc + sn * sn;              // = cc (a2 - 1) + 1 without the cancellation near normal incidence
+    const float D = a2 / (d * d);
+    const float g1 = (2.0f * c) / (c + sqrtf(a2 + (1.0f - a2) * cc));
+    return a2 * D * (g1 * g1);
+}
+
+// radar_algorithms.h:168-187 (model 0); model 1: the lobe above in place of cos^C
+__device__ inline float back_reflection_shader(float incidence_angle, float energy,
+                                               float diffuse, float specular_fac, float specular_exp, int model)
+{
+    float I_specular;
+    if (model == 1) I_specular = ct_lobe(incidence_angle, specular_exp);
+    else {
+        const float IdotR = cosf(incidence_angle);
+        I_specular = powf(IdotR, specular_exp);
+    }
     const float I_total = diffuse * 1.0f + specular_fac * I_specular;
     return I_total * energy;
 }
@@ -506,7 +530,7 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
                 if ((int)mat == P.material_id_air)   // :302
                 {
                     const float incidence_angle = acosf_ref(v_dot(v_neg(dir_in), normal));   // :308
-                    const float ret = back_reflection_shader(incidence_angle, (float)renergy, m.y, m.z, m.w);
+                    const float ret = back_reflection_shader(incidence_angle, (float)renergy, m.y, m.z, m.w, P.brdf_model);
                     if (pass == 0 || P.record_multi_reflection) {   // :319
                         const float time_back = (float)(time * 2.0);
                         sg0.cell = signal_cell((double)time_back, P.resolution);
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
                         const double sensor_view_scalar = (double)v_dot(dir_in, dsh);
                         const float ang = acosf_ref(v_dot(v_neg(rdir), dsh));
                         if (sensor_view_scalar > P.multipath_threshold) {
-                            sg1.strength = back_reflection_shader(ang, (float)renergy, m.y, m.z, m.w);
+                            sg1.strength = back_reflection_shader(ang, (float)renergy, m.y, m.z, m.w, P.brdf_model);
                             sg1.cell = signal_cell(time + time_to_sensor, P.resolution);
                             if (sg1.cell < 0) sg1.cell = -1;
                         }

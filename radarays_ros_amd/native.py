@@ -38,7 +38,7 @@ class RRConfig(C.Structure):
         ("signal_denoising_mb_width", C.c_int32),
         ("ambient_noise", C.c_int32), ("scroll_image", C.c_int32),
         ("record_multi_reflection", C.c_int32), ("record_multi_path", C.c_int32),
-        ("max_waves_per_azimuth", C.c_int32),
+        ("max_waves_per_azimuth", C.c_int32), ("brdf_model", C.c_int32), ("reserved_", C.c_int32),
         ("resolution", C.c_double), ("energy_max", C.c_double), ("signal_max", C.c_double),
         ("signal_denoising_triangular_mode", C.c_double),
         ("signal_denoising_gaussian_mode", C.c_double),
@@ -127,7 +127,7 @@ def lib():
 
 
 def make_config(cfg, n_angles=400, max_waves_per_azimuth=0, wave_energy_threshold=0.001,
-                ray_range_max=1000.0):
+                ray_range_max=1000.0, brdf_model=0):
     """RadarModelConfig (params.py) -> rr_config."""
     c = RRConfig()
     lib().rr_default_config(C.byref(c))
@@ -143,6 +143,7 @@ def make_config(cfg, n_angles=400, max_waves_per_azimuth=0, wave_energy_threshol
     c.record_multi_reflection = int(bool(cfg.record_multi_reflection))
     c.record_multi_path = int(bool(cfg.record_multi_path))
     c.max_waves_per_azimuth = int(max_waves_per_azimuth)
+    c.brdf_model = int(brdf_model)
     for k in ("resolution", "energy_max", "signal_max", "signal_denoising_triangular_mode",
               "signal_denoising_gaussian_mode", "signal_denoising_mb_mode",
               "ambient_noise_at_signal_0", "ambient_noise_at_signal_1",

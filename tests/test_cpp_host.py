@@ -22,7 +22,8 @@ import gen_oracle_images as gen  # noqa: E402
 
 def build_demo():
     if (not os.path.exists(EXE)) or os.path.getmtime(EXE) < max(
-            os.path.getmtime(SRC), os.path.getmtime(os.path.join(ROOT, "include", "radarays_ros_amd", "RadarHIP.hpp"))):
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(ROOT, "include", "radarays_ros_amd", "RadarHIP.hpp")),
+            os.path.getmtime(os.path.join(ROOT, "include", "radarays_mi355.h"))):       # the rr_config layout lives there
         subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE,
                         "-L", os.path.join(ROOT, "radarays_ros_amd"), "-lradarays_mi355",
                         "-Wl,-rpath,$ORIGIN/../../radarays_ros_amd"], check=True)

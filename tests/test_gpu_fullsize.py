@@ -85,9 +85,9 @@ def test_config4_1000_rays(big, native_lib):
 
 
 def test_config5_per_triangle_materials_8_passes(big, native_lib, oracle):
-    """configs[4]'s structure at full size: 10M triangles, one of 8 materials PER TRIANGLE (seed 5),
-    8 passes (its Cook-Torrance BRDF is on the reference's dev/flex branch, not in the checkout: the
-    checkout's A + B cos^C is used).  Properties on the whole frame + the oracle on two azimuths."""
+    """configs[4] at full size: 10M triangles, one of 8 materials PER TRIANGLE (seed 5), 8 passes, Cook-Torrance
+    lobe (rr_config.brdf_model = 1: the build's own specification, the reference's is on its dev/flex branch
+    outside the checkout -- parity unpinned).  Properties on the whole frame + the oracle's twin on two azimuths."""
     _, c = big
     s = scenes.config_scene(5)
     mats = materials_for(s)
@@ -95,7 +95,7 @@ def test_config5_per_triangle_materials_8_passes(big, native_lib, oracle):
     c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
     c.set_materials(mats, s["object_materials"], 0)
     cfg = params.kaist_preset(n_reflections=8, ambient_noise=0)
-    c.set_config(cfg)
+    c.set_config(cfg, 400, brdf_model=1)
     c.set_beam_samples(golden_beams(200))
     pose = scenes.default_pose(s["name"])
     full, _, st = c.simulate(pose)
@@ -110,7 +110,7 @@ def test_config5_per_triangle_materials_8_passes(big, native_lib, oracle):
     for az in ((11, 13), (301, 303)):
         g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
         o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg,
-                                      golden_beams(200), pose, az_begin=az[0], az_end=az[1])
+                                      golden_beams(200), pose, az_begin=az[0], az_end=az[1], brdf_model=1)
         assert gst["wave_passes"] == ost["wave_passes"] and gst["signals"] == ost["signals"], (gst, ost)
         d = image_diff(gf[:, az[0]:az[1]], of[:, az[0]:az[1]], g8[:, az[0]:az[1]], o8[:, az[0]:az[1]])
         assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1, d

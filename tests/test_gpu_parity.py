@@ -39,12 +39,12 @@ def _ctx(native_lib, scene, cfg, mats, beams, noise=None, **kw):
 
 
 def _check(native_lib, oracle, scene, cfg, mats, beams, pose, az=(0, 400), noise=None, use_bvh=-1,
-           mean_tol=MEAN_DEV_TOL):
-    c = _ctx(native_lib, scene, cfg, mats, beams, noise)
+           mean_tol=MEAN_DEV_TOL, brdf_model=0):
+    c = _ctx(native_lib, scene, cfg, mats, beams, noise, brdf_model=brdf_model)
     g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
     sc = oracle.Scene(scene["verts"], scene["faces"], scene["face_object_id"], use_bvh=use_bvh)
     o8, of, ost = oracle.simulate(sc, mats_tuple(mats), scene["object_materials"], cfg, beams, pose,
-                                  noise_rnd=noise, az_begin=az[0], az_end=az[1])
+                                  noise_rnd=noise, az_begin=az[0], az_end=az[1], brdf_model=brdf_model)
     assert gst["overflow"] == 0
     assert gst["wave_passes"] == ost["wave_passes"]
     assert gst["hits"] == ost["hits"]
@@ -100,6 +100,24 @@ def test_multibounce_fresnel_split(native_lib, oracle):
     gold = np.load(os.path.join(GOLDEN, "oracle_multibounce.npz"))["u8"]
     dd = np.abs(g8.astype(int) - gold.astype(int))
     assert dd.max() <= 1 and (dd > 0).mean() < U8_MISMATCH_TOL
+
+
+def test_cook_torrance_lobe_option(native_lib, oracle):
+    """rr_config.brdf_model = 1 (BASELINE.json configs[4]; the build's own GGX / Smith specification -- the
+    reference keeps its Cook-Torrance model on a branch outside the checkout, so this is parity UNPINNED):
+    the GPU follows the oracle's twin of the specification, and the option really changes the image."""
+    s = gen.two_room_scene()
+    mats = [params.RadarMaterial(0.3, 1.0, 0.0, 1.0), params.RadarMaterial(0.0, 0.3, 0.7, 40.0),
+            params.RadarMaterial(0.12, 0.5, 0.5, 6.0)]
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=0, record_multi_path=True)
+    pose = scenes.default_pose("box12")
+    _, ct8, _ = _check(native_lib, oracle, s, cfg, mats, golden_beams(64), pose, brdf_model=1)
+    _, ph8, _ = _check(native_lib, oracle, s, cfg, mats, golden_beams(64), pose, brdf_model=0)
+    assert (ct8 != ph8).mean() > 0.01
+    c = native_lib.Context(0)
+    with pytest.raises(native_lib.RRError, match="brdf_model"):
+        c.set_config(cfg, 400, brdf_model=2)
+    c.close()
 
 
 def test_perlin_noise_and_scroll(native_lib, oracle):
