@@ -105,7 +105,8 @@ def main():
     cfg = params.kaist_preset(n_reflections=n_pass, n_samples=n_rays, ambient_noise=args.ambient_noise)
     mats = materials_for(scene)
     beams = golden_beams(n_rays)
-    noise = (np.random.RandomState(7).uniform(0, 1, params.N_ANGLES) * 1000.0).astype(np.float32)
+    # fresh offsets per frame of a step like the reference draws them (RadarCPU.cpp:461-472): 16 rows, frame f -> row f % 16
+    noise = (np.random.RandomState(7).uniform(0, 1, 16 * params.N_ANGLES) * 1000.0).astype(np.float32)
     poses = scenes.trajectory(16, scene["name"])
 
     ctx = native.Context(local_rank)
@@ -258,7 +259,7 @@ def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
 
     def frame(k, nt):
         _, _, st = O.simulate(sc, m, scene["object_materials"], cfg, beams, poses[k % len(poses)],
-                              noise_rnd=noise, want_f32=False, n_threads=nt, brdf_model=brdf_model)
+                              noise_rnd=noise[:400], want_f32=False, n_threads=nt, brdf_model=brdf_model)
         return st["seconds"]
 
     # the reference parallelises azimuths with OpenMP (RadarCPU.cpp:155); pick the thread

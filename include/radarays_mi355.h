@@ -130,7 +130,9 @@ int rr_set_config(rr_ctx* ctx, const rr_config* cfg);
 int rr_set_beam_samples(rr_ctx* ctx, const float* dirs /*[n][3]*/, size_t n);
 
 /* per-azimuth `random_begin` of the ambient-noise stage (RadarCPU.cpp:472);
- * [n_angles].  Needed only when ambient_noise != 0. */
+ * [n_angles].  Needed only when ambient_noise != 0.  The reference draws fresh offsets for every frame
+ * (RadarCPU.cpp:461-472): a caller of the single-frame entry points sets a new row before each frame; for
+ * the batch entry points n may be k * n_angles (k >= 2 rows), frame f of a batch then uses row f % k. */
 int rr_set_noise_offsets(rr_ctx* ctx, const float* rnd, size_t n);
 
 /* include_motion = true (RadarCPU.cpp:190-196, cfg/RadarModel.cfg:85): the reference looks

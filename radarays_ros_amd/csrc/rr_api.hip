@@ -102,6 +102,7 @@ struct rr_ctx {
     bool have_materials = false;
     std::vector<float> beams;   // xyz
     std::vector<float> noise;
+    int noise_rows = 1;
     std::vector<float> motion;   // [n_angles][7] or empty
     std::vector<float> smear;
     int smear_mode = 0;
@@ -279,7 +280,11 @@ int upload_tables(rr_ctx* c)
     }
 
     if (dirty & (rr_ctx::D_NOISE | rr_ctx::D_CFG)) {
-    std::vector<float> nz((size_t)g.n_angles, 0.0f);
+    // one row of n_angles offsets, or k rows: frame f of a batch then takes row f % k (the reference draws
+    // fresh offsets for every frame, RadarCPU.cpp:461-472)
+    const size_t A = (size_t)g.n_angles;
+    c->noise_rows = (c->noise.size() >= 2 * A && c->noise.size() % A == 0) ? (int)(c->noise.size() / A) : 1;
+    std::vector<float> nz((size_t)c->noise_rows * A, 0.0f);
     for (size_t i = 0; i < nz.size() && i < c->noise.size(); i++) nz[i] = c->noise[i];
     RR_HIP(c, c->d_noise.ensure(nz.size()));
     RR_HIP(c, hipMemcpy(c->d_noise.p, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -362,7 +367,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.nodes = c->d_nodes.p; P.tris = c->d_tris.p;
     P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.beam_order2 = c->d_beam_order2.p; P.materials = c->d_materials.p;
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
-    P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr;
+    P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr; P.noise_rows = c->noise_rows;
     P.decay = c->d_decay.p;
     P.motion_poses = c->motion.empty() ? nullptr : c->d_motion.p;
     for (int k = 0; k < 2; k++) {

@@ -88,7 +88,8 @@ struct Params {
     const float4* materials;     // [n_materials] velocity, ambient, diffuse, specular
     const int32_t* object_materials;
     const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)
-    const float* noise_rnd;      // [n_angles] or null
+    const float* noise_rnd;      // [noise_rows][n_angles] or null; frame f of a batch reads row f % noise_rows
+    int noise_rows;
     int mat_stride;              // material sets: frame f shades with materials[f * mat_stride + id] (0: one table)
     int share_first;             // material sets: every frame has the pose of frame 0, pass 0 is traced once
     const float* decay;          // [n_cells] expf(-energy_loss * bin range), ambient noise floor

@@ -925,7 +925,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     const int angle_id = P.az_begin + seg % P.n_loc;
     const int col = (P.scroll + angle_id) % P.n_angles;   // :457 (placement is done by the assemble step)
     const float final_scale = (float)(P.signal_max / (double)max_val);   // :533
-    const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[angle_id] : 0.0f;
+    const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[(size_t)((seg / P.n_loc) % P.noise_rows) * P.n_angles + angle_id] : 0.0f;
     PerlinCol pc1 = { 0.0, nullptr, nullptr }, pc2 = pc1;
     if (P.ambient_noise == 2) {   // the signal chunk is dead (barriers above): its LDS holds the column tables now
         double2* tab = reinterpret_cast<double2*>(s_union);

@@ -393,6 +393,17 @@ def test_frame_batch_equals_single_frames(native_lib):
         assert np.array_equal(block[f].cpu().numpy().T, one[:, b:e]), f
     with pytest.raises(native_lib.RRError, match="frame batch"):
         c.simulate_batch_columns_device(np.tile(poses[0], (65, 1)), b, e, block.data_ptr(), st)
+    # k rows of noise offsets: frame f of a batch takes row f % k (fresh noise per frame, RadarCPU.cpp:461-472)
+    rows = (np.random.RandomState(9).uniform(0, 1, (2, 400)) * 1000).astype(np.float32)
+    c.set_noise_offsets(rows.ravel())
+    c.simulate_batch_columns_device(poses, b, e, block.data_ptr(), st)
+    torch.cuda.synchronize()
+    got = block.cpu().numpy()
+    for f, p in enumerate(poses):
+        c.set_noise_offsets(rows[f % 2])
+        one, _, _ = c.simulate(p, b, e)
+        assert np.array_equal(got[f].T, one[:, b:e]), f
+    assert not np.array_equal(got[0], got[1])
     c.close()
 
 
