@@ -354,6 +354,7 @@ __device__ inline void fresnel_split(V3 n, const V3 d, const double energy, cons
     const double incidence_angle = (double)acosf_ref(v_dot(v_neg(d), n));
     rdir = v_add(d, v_scale(v_scale(n, 2.0f), v_dot(v_neg(n), d)));   // :73
     tdir = { 0.0f, 0.0f, 0.0f };
+    bool transmitted = false;          // false: tdir stays the zero vector of radar_algorithms.h:66
     if (n1 > 0.0) {
         const double n21 = n2 / n1;
         double angle_limit = 100.0;
@@ -365,10 +366,13 @@ __device__ inline void fresnel_split(V3 n, const V3 d, const double energy, cons
                 const double c = cos(incidence_angle);
                 tdir = v_add(v_scale(d, (float)n12),
                              v_scale(n, (float)(n12 * c - sqrt(1 - n12 * n12 * (1 - c * c)))));   // :100
+                transmitted = true;
             }
         }
     }
-    const double refraction_angle = (double)acosf_ref(v_dot(tdir, v_neg(n)));   // :106
+    // :106.  For the zero vector the dot product is (+-)0 and acosf(+-0) is the f32 value of pi/2: no need to
+    // run the f64 acos for every wave that meets an opaque material (v = 0: the KAIST wall) or total reflection
+    const double refraction_angle = transmitted ? (double)acosf_ref(v_dot(tdir, v_neg(n))) : (double)1.57079637050628662109375f;
     double rs, rp;
     const double eps = 0.0001;
     const double s = incidence_angle + refraction_angle;
