@@ -126,6 +126,7 @@ struct rr_ctx {
 
     bool stats_mode = false;
     int pass0_az = 16;
+    int stack_lds_max = 64;      // traversal stack entries kept in LDS (RR_STACK_LDS lowers it: tests of the spill path)
     int timing = 0;   // 0 off, 1 every kernel, 2 k_trace only
     std::map<std::string, KernelTimer> timers;
 };
@@ -331,9 +332,13 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     RR_HIP(c, L.d_cols_u8.ensure(S * g.n_cells));
     if (want_f32) RR_HIP(c, L.d_cols_f32.ensure(S * g.n_cells));
     // traversal stack: LDS part + spill
-    L.stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 64));   // 64 B of LDS per entry per wave
+    L.stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, (uint32_t)c->stack_lds_max));   // 64 B of LDS per entry per wave
     const int spill_depth = (int)c->stack_need - L.stack_lds;
-    const size_t threads = S * (size_t)((cap + 63) / 64) * 64;
+    // one spill column per ray slot a launch can address: later passes ceil(cap/32)*32 slots per segment,
+    // pass 0 its (sample x azimuth) tiles, whose padding can exceed S * n_beam (e.g. ONE segment: 16 x n_beam)
+    const size_t A0 = (size_t)c->pass0_az, Sw0 = 16 / A0;
+    const size_t slots0 = ((((S + A0 - 1) / A0) * (((size_t)n_beam + Sw0 - 1) / Sw0) + 1) / 2) * 32;
+    const size_t threads = std::max(S * (size_t)((cap + 63) / 64) * 64, slots0);
     L.spill_stride = (int)threads;
     if (spill_depth > 0) RR_HIP(c, L.d_spill.ensure((size_t)spill_depth * threads));
     else RR_HIP(c, L.d_spill.ensure(1));
@@ -522,6 +527,7 @@ rr_ctx* rr_create(int device)
     c->stream_lanes = getenv("RR_STREAM_LANES") ? std::max(1, std::min(atoi(getenv("RR_STREAM_LANES")), n_lanes))
                                                 : std::min(3, n_lanes);
     if (getenv("RR_PASS0_AZ")) { const int a = atoi(getenv("RR_PASS0_AZ")); if (a == 1 || a == 2 || a == 4 || a == 8 || a == 16) c->pass0_az = a; }
+    if (getenv("RR_STACK_LDS")) c->stack_lds_max = std::max(1, std::min(64, atoi(getenv("RR_STACK_LDS"))));
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1020,7 +1026,7 @@ int rr_debug_trace(rr_ctx* c, const float* origs, const float* dirs, size_t n, f
     if (!origs || !dirs || !out_t || !out_face) return fail(c, -3, "rr_debug_trace: null pointer");
     RR_HIP(c, hipSetDevice(c->device));
     const size_t chunk = 1u << 16;
-    const int stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, 64));
+    const int stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, (uint32_t)c->stack_lds_max));
     const int spill_depth = (int)c->stack_need - stack_lds;
     DevBuf<float> d_o, d_d, d_t; DevBuf<uint32_t> d_f, d_spill;
     RR_HIP(c, d_o.ensure(3 * chunk)); RR_HIP(c, d_d.ensure(3 * chunk)); RR_HIP(c, d_t.ensure(chunk));

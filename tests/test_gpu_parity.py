@@ -102,6 +102,33 @@ def test_multibounce_fresnel_split(native_lib, oracle):
     assert dd.max() <= 1 and (dd > 0).mean() < U8_MISMATCH_TOL
 
 
+def test_traversal_stack_spill_path(native_lib, oracle, monkeypatch):
+    """With only 2 (then 1) stack entries in LDS every deeper entry of the traversal stack goes through the
+    HBM spill buffer (RR_STACK_LDS is read at rr_create): same hits, same frames -- single-azimuth windows
+    included, where the pass-0 tiles address 16 x n_beam ray slots for one segment."""
+    s = scenes.heightfield_room(40, n_buildings=30)        # 3.6k triangles: a tree deep enough to spill for real
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=0)
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    pose = scenes.default_pose(s["name"])
+    for lds_entries in ("2", "1"):
+        monkeypatch.setenv("RR_STACK_LDS", lds_entries)
+        _check(native_lib, oracle, s, cfg, mats, golden_beams(200), pose, az=(0, 40), use_bvh=1)
+        _check(native_lib, oracle, s, cfg, mats, golden_beams(200), pose, az=(7, 8), use_bvh=1)
+        c = _ctx(native_lib, s, cfg, mats, golden_beams(48))
+        assert c.bvh_info()["stack_need"] > 4
+        rs = np.random.RandomState(4)
+        o = (rs.uniform(-150, 150, (2000, 3)) * np.array([1, 1, 0.02]) + np.array([0, 0, 8])).astype(np.float32)
+        d = rs.normal(size=(2000, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        t, f = c.debug_trace(o, d)
+        c.close()
+        monkeypatch.delenv("RR_STACK_LDS")
+        c = _ctx(native_lib, s, cfg, mats, golden_beams(48))
+        t2, f2 = c.debug_trace(o, d)
+        c.close()
+        assert np.array_equal(t, t2) and np.array_equal(f, f2)
+
+
 def test_cook_torrance_lobe_option(native_lib, oracle):
     """rr_config.brdf_model = 1 (BASELINE.json configs[4]; the build's own GGX / Smith specification -- the
     reference keeps its Cook-Torrance model on a branch outside the checkout, so this is parity UNPINNED):
