@@ -129,15 +129,30 @@ def main():
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
-    # one instrumented frame outside the timed region: wave-pass count of this workload
+    # ---- instrumentation, all of it outside (and before) the timed region ---------------------------------
+    # one step: wave-pass count of this workload
     step(0)
     torch.cuda.synchronize()
     st = ctx.stats()
     wave_passes_frame_rank = st["wave_passes"]
     assert st["overflow"] == 0, st
-
-    ctx.set_timing_mode(2)          # hipEvents around k_trace only, on the launch stream
+    # one step with the counting build of k_trace: measured node / triangle fetches per wave-pass
+    ctx.set_stats_mode(True)
+    step(0)
+    torch.cuda.synchronize()
+    st2 = ctx.stats()
+    ctx.set_stats_mode(False)
+    # k_trace alone on the GPU (one step at a time, nothing else in flight): the kernel's own speed, as
+    # opposed to its duration while 4 steps share the chip in the timed region below
+    ctx.set_timing_mode(2)
     ctx.kernel_time("trace", reset=True)
+    for k in range(12):
+        step(k)
+        torch.cuda.synchronize()
+    iso_ms, iso_launches = ctx.kernel_time("trace", reset=True)
+
+    # ---- the timed region: exactly `steps` steps between two synchronisation points ------------------------
+    # (timing mode 2 stays on: hipEvents around k_trace only, on the launch stream)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -150,20 +165,6 @@ def main():
     t1 = time.perf_counter()
     trace_ms, trace_launches = ctx.kernel_time("trace", reset=True)
     ctx.set_timing_mode(0)
-    # k_trace alone on the GPU (one step at a time, nothing else in flight): the kernel's own speed, as
-    # opposed to its duration while 4 steps share the chip in the timed region above
-    ctx.set_timing_mode(2)
-    for k in range(12):
-        step(k)
-        torch.cuda.synchronize()
-    iso_ms, iso_launches = ctx.kernel_time("trace", reset=True)
-    ctx.set_timing_mode(0)
-    # one instrumented step outside the timed region: measured node / triangle fetches per wave-pass
-    ctx.set_stats_mode(True)
-    step(0)
-    torch.cuda.synchronize()
-    st2 = ctx.stats()
-    ctx.set_stats_mode(False)
 
     elapsed = t1 - t0
     if world > 1:
