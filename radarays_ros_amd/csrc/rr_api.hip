@@ -28,6 +28,7 @@ bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t
                     std::string& err, hipStream_t stream);
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s);
+void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s);
 }  // namespace rr
 
 using namespace rr;
@@ -88,8 +89,10 @@ struct rr_ctx {
 
     // scene
     bool have_mesh = false;
-    DevBuf<Node4> d_nodes;
-    DevBuf<TriRec> d_tris;
+    // ONE allocation: the BVH4 nodes, then the leaf-order triangles -- child references are float4 offsets
+    // from its base (rr_bvh.h), so a traversal step forms its address the same way for a node and a leaf
+    DevBuf<float4> d_bvh;
+    uint32_t tri_base4 = 0;        // float4 offset of triangle 0
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t depth = 0, stack_need = 0;
 
@@ -369,7 +372,8 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
 {
     const rr_config& g = c->cfg;
     std::memset(&P, 0, sizeof(P));
-    P.nodes = c->d_nodes.p; P.tris = c->d_tris.p;
+    P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
+    P.tri_base4 = c->tri_base4;
     P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.beam_order2 = c->d_beam_order2.p; P.materials = c->d_materials.p;
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr; P.noise_rows = c->noise_rows;
@@ -418,6 +422,14 @@ struct TimedScope {
         if (on) { (void)hipEventRecord(b, s); c->timers[name].pending.emplace_back(a, b); }
     }
 };
+
+// child references are 28-bit float4 offsets from the base of the tree allocation (rr_bvh.h)
+int check_bvh_size(rr_ctx* c, size_t n_nodes, size_t n_tris)
+{
+    if (n_nodes * 8 + (n_tris + 4) * 3 >= (1ull << 28))
+        return fail(c, -4, "rr_set_mesh: tree too large for 28-bit references (8 x nodes + 3 x triangles must stay below 2^28: about 60M triangles)");
+    return 0;
+}
 
 int check_ready(rr_ctx* c)
 {
@@ -545,7 +557,7 @@ void rr_destroy(rr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();   // frames may still be in flight on the lanes' or the caller's streams
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    c->d_nodes.release(); c->d_tris.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
+    c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
     c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_beam_order2.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -573,11 +585,17 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     // frames in flight on the lane streams or a caller's stream (all non-blocking: a blocking hipMemcpy
     // does not order against them) still trace the old tree
     RR_HIP(c, hipDeviceSynchronize());
-    RR_HIP(c, c->d_nodes.ensure(bvh.nodes.size()));
-    RR_HIP(c, hipMemcpy(c->d_nodes.p, bvh.nodes.data(), bvh.nodes.size() * sizeof(Node4), hipMemcpyHostToDevice));
-    RR_HIP(c, c->d_tris.ensure(bvh.tris.size() + 4));   // +4: a quad may fetch past a short leaf
-    if (!bvh.tris.empty())
-        RR_HIP(c, hipMemcpy(c->d_tris.p, bvh.tris.data(), bvh.tris.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+    {
+        const size_t nn = bvh.nodes.size(), nt = bvh.tris.size();
+        int rc = check_bvh_size(c, nn, nt); if (rc) return rc;
+        c->tri_base4 = (uint32_t)(nn * 8);
+        RR_HIP(c, c->d_bvh.ensure(nn * 8 + (nt + 4) * 3));   // +4 triangles: a quad may fetch past a short leaf
+        RR_HIP(c, hipMemcpy(c->d_bvh.p, bvh.nodes.data(), nn * sizeof(Node4), hipMemcpyHostToDevice));
+        if (nt) RR_HIP(c, hipMemcpy(c->d_bvh.p + c->tri_base4, bvh.tris.data(), nt * sizeof(TriRec), hipMemcpyHostToDevice));
+        launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr);
+        RR_HIP(c, hipGetLastError());
+        RR_HIP(c, hipDeviceSynchronize());
+    }
     c->n_nodes = bvh.nodes.size(); c->n_tris = bvh.tris.size();
     c->depth = bvh.depth; c->stack_need = bvh.stack_need;
     c->have_mesh = true;
@@ -597,9 +615,23 @@ int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* fa
     std::string err;
     if (!build_bvh4_gpu(verts, nv, faces, nf, face_object_id, &dn, &nn, &dt, &depth, &need, &inflate, err, c->stream))
         return fail(c, -4, err);
-    c->d_nodes.release(); c->d_tris.release();
-    c->d_nodes.p = dn; c->d_nodes.n = nf + 1;
-    c->d_tris.p = dt; c->d_tris.n = nf + 4;
+    {
+        // the builder hands over two arrays: move them into the one allocation the traversal addresses
+        int rc = check_bvh_size(c, nn, nf);
+        hipError_t e = hipSuccess;
+        if (!rc) {
+            c->tri_base4 = (uint32_t)(nn * 8);
+            e = c->d_bvh.ensure(nn * 8 + (nf + 4) * 3);
+            if (e == hipSuccess) e = hipMemcpy(c->d_bvh.p, dn, nn * sizeof(Node4), hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c->d_bvh.p + c->tri_base4, dt, nf * sizeof(TriRec), hipMemcpyDeviceToDevice);
+        }
+        (void)hipFree(dn); (void)hipFree(dt);
+        if (rc) return rc;
+        RR_HIP(c, e);
+        launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr);
+        RR_HIP(c, hipGetLastError());
+        RR_HIP(c, hipDeviceSynchronize());
+    }
     c->n_nodes = nn; c->n_tris = nf; c->depth = depth; c->stack_need = need;
     c->have_mesh = true;
     for (Lane& L : c->lanes) L.buf_seg = 0;
@@ -1032,7 +1064,8 @@ int rr_debug_trace(rr_ctx* c, const float* origs, const float* dirs, size_t n, f
     RR_HIP(c, d_o.ensure(3 * chunk)); RR_HIP(c, d_d.ensure(3 * chunk)); RR_HIP(c, d_t.ensure(chunk));
     RR_HIP(c, d_f.ensure(chunk)); RR_HIP(c, d_spill.ensure(spill_depth > 0 ? (size_t)spill_depth * chunk : 1));
     Params P; std::memset(&P, 0, sizeof(P));
-    P.nodes = c->d_nodes.p; P.tris = c->d_tris.p; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
+    P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
+    P.tri_base4 = c->tri_base4; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
     P.spill = d_spill.p; P.spill_stride = (int)chunk; P.stack_lds = stack_lds; P.spill_depth = std::max(0, spill_depth);
     int rc = 0;
     for (size_t b = 0; b < n && !rc; b += chunk) {

@@ -13,10 +13,14 @@
 
 namespace rr {
 
-// child reference encoding
+// child reference encoding AS BUILT (host and GPU builders):
 //   inner : node index (< 0x80000000)
 //   leaf  : 0x80000000 | (count-1) << 28 | first_triangle   (count 1..8, first < 2^28)
 //   empty : box = degenerate point at kEmptyCoord (never hit), ref = kEmptyRef
+// ON THE DEVICE the low 28 bits are re-encoded once per upload (k_encode_refs) as the float4 offset of the
+// child from the base of the ONE allocation that holds the nodes and then the triangles:
+//   inner : node index * 8                         leaf : tri_base4 + first_triangle * 3   (flag and count kept)
+// so a traversal step forms `base + offset + lane part` the same way whatever the child is.
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0x7FFFFFFFu;
 constexpr uint32_t kMaxLeafTris = 4;

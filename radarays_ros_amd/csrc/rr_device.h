@@ -78,8 +78,9 @@ struct SegStats { uint32_t wave_passes, hits, signals, pad; };
 
 struct Params {
     // scene
-    const Node4* nodes;
-    const TriRec* tris;
+    const Node4* nodes;          // base of the tree allocation: nodes, then triangles
+    const TriRec* tris;          // = (TriRec*)((float4*)nodes + tri_base4)
+    uint32_t tri_base4;          // float4 offset of triangle 0 from `nodes`
     // per-config tables
     const float4* q_as;          // [n_angles] Tas.R (RadarCPU.cpp:202)
     const float4* beams;         // [n_beam] xyz

@@ -87,7 +87,7 @@ __device__ inline RaySetup ray_setup(V3 o, V3 d)
 }
 
 template <bool STATS, bool SPILL>
-__device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __restrict__ tris,
+__device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t tri_base4,
                                const RaySetup& R, float range_max,
                                uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gray,
                                unsigned& n_nodes, unsigned& n_tris, unsigned* wstat = nullptr)
@@ -105,8 +105,9 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     int sp = 0;
     uint32_t cur = 0;   // root
 
-    const float4* node4 = reinterpret_cast<const float4*>(nodes);   // 8 float4 per node, 2 per child
-    const float4* tri4 = reinterpret_cast<const float4*>(tris);     // 3 float4 per triangle
+    // child references are float4 offsets from base4 (nodes: 8 float4, 2 per child; triangles: 3 float4):
+    // lane q adds 2q (its child record) or 3q (its triangle)
+    const uint32_t q2 = 2u * (uint32_t)q, q3 = 3u * (uint32_t)q;
     const int qsh = (threadIdx.x & 63) & ~3;                        // bit position of this quad in a ballot
     uint32_t misskey = 0x7F800000u | (uint32_t)q;                   // key of a missed child
     asm volatile("" : "+v"(misskey));                              // opaque: keeps (tmin & ~3) | q one v_and_or_b32
@@ -117,9 +118,9 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
             wstat[0]++; wstat[1] += __ballot(!leaf) != 0ull; wstat[2] += __ballot(leaf) != 0ull;
             wstat[3] += (unsigned)__builtin_popcountll(__ballot(true)) >> 2;
         }
-        const uint32_t first = cur & 0x0FFFFFFFu;
+        const uint32_t first = cur & 0x0FFFFFFFu;                   // float4 offset of the node / of the leaf's first triangle
         const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-        const float4* p = leaf ? (tri4 + 3 * (size_t)(first + q)) : (node4 + 8 * (size_t)cur + 2 * q);
+        const float4* p = base4 + (first + (leaf ? q3 : q2));
         const float4 A = p[0], B = p[1];
         float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
         if (leaf) C = p[2];          // triangle arrays are padded: q >= cnt reads stay in bounds
@@ -200,7 +201,7 @@ __device__ inline Hit traverse(const Node4* __restrict__ nodes, const TriRec* __
     best.t = __uint_as_float((uint32_t)(bestkey >> 32));
     const bool hit = (uint32_t)(bestkey >> 32) < 0x7F800000u;
     best.face = hit ? ((uint32_t)bestkey >> 2) : 0xFFFFFFFFu;
-    best.tri = hit ? best_first + ((uint32_t)bestkey & 3u) : 0xFFFFFFFFu;
+    best.tri = hit ? (best_first - tri_base4) / 3u + ((uint32_t)bestkey & 3u) : 0xFFFFFFFFu;   // leaf-order triangle index
     return best;
 }
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         R.idx = s_ray[6][r]; R.idy = s_ray[7][r]; R.idz = s_ray[8][r];
         R.oox = s_ray[9][r]; R.ooy = s_ray[10][r]; R.ooz = s_ray[11][r];
         const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
-        const Hit h = traverse<STATS, SPILL>(P.nodes, P.tris, R, P.range_max, lds_stack, P.stack_lds,
+        const Hit h = traverse<STATS, SPILL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, c
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
     const RaySetup R = ray_setup(o, d);
-    const Hit h = traverse<false, true>(P.nodes, P.tris, R, P.range_max, lds_stack, P.stack_lds,
+    const Hit h = traverse<false, true>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
     if ((threadIdx.x & 3) == 0) {
         out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
@@ -1069,6 +1070,25 @@ __global__ __launch_bounds__(256) void k_assemble_u8x4(const uint8_t* __restrict
 // ---------------------------------------------------------------------------
 // launchers (called from rr_api.cpp through plain C++ prototypes)
 // ---------------------------------------------------------------------------
+// once per tree upload: builder references (node index / first triangle) -> float4 offsets from the
+// base of the tree allocation (rr_bvh.h)
+__global__ void k_encode_refs(Node4* nodes, size_t n_children, uint32_t tri_base4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_children) return;
+    uint32_t& ref = nodes[i >> 2].c[i & 3].ref;
+    const uint32_t r = ref;
+    if (r == kEmptyRef) return;
+    if (r & kLeafFlag) ref = (r & 0xF0000000u) | (tri_base4 + 3u * (r & 0x0FFFFFFFu));
+    else ref = r * 8u;
+}
+void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s)
+{
+    const size_t n = n_nodes * 4;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_encode_refs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nodes, n, tri_base4);
+}
+
 void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int n_seg = (pass == 0 && P.share_first) ? P.n_loc : P.n_seg;
