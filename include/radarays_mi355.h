@@ -101,7 +101,8 @@ int     rr_abi_version(void);
 
 /* Replaces rm::import_embree_map (src/radar_simulator.cpp:149): triangle soup
  * + per-face object id (index into object_materials; NULL -> all 0).  Builds
- * the BVH on the host and uploads it.  Inputs are copied. */
+ * the BVH on the host and uploads it.  Inputs are copied.  Size limit: 8 x BVH4 nodes + 3 x triangles
+ * < 2^28 (child references are 28-bit offsets), i.e. about 60M triangles. */
 int rr_set_mesh(rr_ctx* ctx, const float* verts /*[nv][3]*/, size_t nv,
                 const uint32_t* faces /*[nf][3]*/, size_t nf,
                 const uint32_t* face_object_id /*[nf] or NULL*/);
