@@ -55,20 +55,19 @@ def test_target_config_properties(big, native_lib):
     assert np.array_equal(np.roll(full, 123, axis=1), rolled)
 
 
-def test_target_config_oracle_spot_check(big, native_lib, oracle):
+def test_target_config_full_frame_vs_oracle(big, native_lib, oracle):
     s, c = big
     cfg = params.kaist_preset(n_reflections=4, ambient_noise=0)
     c.set_config(cfg)
     c.set_beam_samples(golden_beams(200))
     pose = scenes.default_pose(s["name"])
+    # the WHOLE frame of the north-star target (10M triangles, 4 passes, 200 rays) against the oracle
     sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=1)
-    for az in ((37, 39), (250, 252)):
-        g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
-        o8, of, ost = oracle.simulate(sc, mats_tuple(materials_for(s)), s["object_materials"], cfg,
-                                      golden_beams(200), pose, az_begin=az[0], az_end=az[1])
-        assert gst["wave_passes"] == ost["wave_passes"] and gst["signals"] == ost["signals"]
-        d = image_diff(gf[:, az[0]:az[1]], of[:, az[0]:az[1]], g8[:, az[0]:az[1]], o8[:, az[0]:az[1]])
-        assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1, d
+    g8, gf, gst = c.simulate(pose, want_f32=True)
+    o8, of, ost = oracle.simulate(sc, mats_tuple(materials_for(s)), s["object_materials"], cfg, golden_beams(200), pose)
+    assert gst["wave_passes"] == ost["wave_passes"] and gst["hits"] == ost["hits"] and gst["signals"] == ost["signals"]
+    d = image_diff(gf, of, g8, o8)
+    assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1 and d["u8_mismatch_frac"] <= 1e-3, d
 
 
 def test_config4_1000_rays(big, native_lib):

@@ -180,12 +180,14 @@ def test_config2_full_frame_100k(native_lib, oracle):
     assert (g8 > 0).mean() > 0.05
 
 
-def test_config3_subset_1m_tris_4_passes(native_lib, oracle):
-    """BASELINE.json configs[2] on a 40-azimuth subset (the oracle needs seconds, not minutes)."""
+def test_config3_full_frame_1m_tris_4_passes(native_lib, oracle):
+    """BASELINE.json configs[2], the WHOLE 400 x 3424 frame (864k wave-passes) against the oracle: wave, hit and
+    signal counts exact, mean |f32 deviation| / 255 <= 1e-5 over all 1.37M pixels (north_star allows 1e-3)."""
     s = scenes.config_scene(3)
     cfg = params.kaist_preset(n_reflections=4, ambient_noise=0)
-    for az in ((0, 20), (190, 210)):
-        _check(native_lib, oracle, s, cfg, materials_for(s), golden_beams(200), scenes.default_pose(s["name"]), az)
+    d, g8, _ = _check(native_lib, oracle, s, cfg, materials_for(s), golden_beams(200), scenes.default_pose(s["name"]),
+                      use_bvh=1)
+    assert (g8 > 0).mean() > 0.05
 
 
 def test_include_motion_per_azimuth_poses(native_lib, oracle):
