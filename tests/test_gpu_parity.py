@@ -180,6 +180,32 @@ def test_config2_full_frame_100k(native_lib, oracle):
     assert (g8 > 0).mean() > 0.05
 
 
+def test_bench_step_against_oracle(native_lib, oracle):
+    """What bench.py times, checked directly: ONE rr_simulate_batch_device call renders the 16-pose trajectory
+    of config 2 (400 x 200 rays, 100k triangles, Perlin noise with one row of offsets per frame); every mono8
+    image against the oracle's frame for that pose and that row."""
+    import torch
+    s = scenes.config_scene(2)
+    cfg = params.kaist_preset(n_reflections=1, n_samples=200, ambient_noise=2)
+    mats = materials_for(s)
+    noise = (np.random.RandomState(7).uniform(0, 1, (16, 400)) * 1000.0).astype(np.float32)
+    poses = scenes.trajectory(16, s["name"])
+    c = _ctx(native_lib, s, cfg, mats, golden_beams(200), noise=noise.ravel())
+    imgs = torch.zeros((16, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    sp = torch.cuda.current_stream().cuda_stream
+    c.simulate_batch_device(poses, imgs.data_ptr(), sp)
+    c.synchronize(sp)
+    got = imgs.cpu().numpy()
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=1)
+    for f, p in enumerate(poses):
+        o8, _, _ = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, golden_beams(200), p,
+                                   noise_rnd=noise[f], want_f32=False)
+        d8 = np.abs(got[f].astype(np.int32) - o8.astype(np.int32))
+        assert d8.max() <= 1 and (d8 > 0).mean() <= U8_MISMATCH_TOL, (f, int(d8.max()), float((d8 > 0).mean()))
+    c.close()
+
+
 def test_config3_full_frame_1m_tris_4_passes(native_lib, oracle):
     """BASELINE.json configs[2], the WHOLE 400 x 3424 frame (864k wave-passes) against the oracle: wave, hit and
     signal counts exact, mean |f32 deviation| / 255 <= 1e-5 over all 1.37M pixels (north_star allows 1e-3)."""
