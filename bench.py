@@ -35,7 +35,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -88,7 +87,7 @@ def main():
     import torch.distributed as dist
     from radarays_ros_amd import native, params, scenes
     from radarays_ros_amd.dist import AzimuthShard
-    from common import golden_beams, materials_for
+    from radarays_ros_amd.fixtures import golden_beams, materials_for
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")

@@ -229,7 +229,8 @@ int rr_set_stats_mode(rr_ctx* ctx, int enable);
 /* nearest-hit query for rays given in map coordinates (device traversal). */
 int rr_debug_trace(rr_ctx* ctx, const float* origs /*[n][3]*/, const float* dirs /*[n][3]*/, size_t n,
                    float* out_t /*[n], <0 = miss*/, uint32_t* out_face /*[n]*/);
-/* BVH facts: nodes, leaf triangles, depth, stack entries needed. */
+/* BVH facts: nodes, leaf triangle records (>= faces: the host builder may cut a face by spatial splits and keeps
+ * one record per part, at most twice the faces), depth, stack entries needed. */
 int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* depth, uint32_t* stack_need);
 /* average duration (ms) of the trace kernel launches since the last call with
  * reset!=0, measured with hipEvents on the launch stream when timing mode is

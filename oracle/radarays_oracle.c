@@ -22,6 +22,7 @@
 #include "radarays_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
@@ -774,6 +775,10 @@ static int simulate_impl(const orc_scene* scene,
     uint64_t tot_wp = 0, tot_hits = 0, tot_sig = 0, tot_nodes = 0, tot_tris = 0;
     int err = 0;
 
+    /* tooling only (tools/treeq: BVH-quality study on real ray sets): ORC_RAYLOG=<file> appends every cast ray
+     * as { int32 azimuth, int32 pass, float o[3], float d[3] } in map coordinates */
+    FILE* raylog = getenv("ORC_RAYLOG") ? fopen(getenv("ORC_RAYLOG"), "ab") : NULL;
+
     const double t_start = now_s();   /* RadarCPU.cpp:147-148 */
 
 #ifdef _OPENMP
@@ -823,6 +828,12 @@ static int simulate_impl(const orc_scene* scene,
                 const v3 d_m = q_rot(q_am, wave.dir);
                 float wave_range; uint32_t f;
                 tot_wp++;
+                if (raylog) {
+                    const int32_t hd[2] = { angle_id, pass_id };
+                    const float od[6] = { o_m.x, o_m.y, o_m.z, d_m.x, d_m.y, d_m.z };
+                    #pragma omp critical(raylog)
+                    { fwrite(hd, sizeof hd, 1, raylog); fwrite(od, sizeof od, 1, raylog); }
+                }
                 if (!scene_intersect(scene, o_m, d_m, &wave_range, &f, &st)) continue;   /* :252 */
                 tot_hits++;
                 const uint32_t obj_id = scene->obj[f];
@@ -988,6 +999,7 @@ static int simulate_impl(const orc_scene* scene,
     }
 
     const double t_stop = now_s();   /* :550 */
+    if (raylog) fclose(raylog);
     free(w);
     if (stats) {
         stats->wave_passes = tot_wp; stats->hits = tot_hits; stats->signals = tot_sig;

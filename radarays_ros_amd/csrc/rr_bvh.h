@@ -50,18 +50,28 @@ static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
 struct Bvh4 {
     std::vector<Node4> nodes;   // nodes[0] is the root
-    std::vector<TriRec> tris;   // leaf order
+    std::vector<TriRec> tris;   // leaf order; a face cut by spatial splits has one record per leaf that holds a part of it
     uint32_t depth = 0;         // node levels on the longest root->leaf path
     uint32_t stack_need = 0;    // upper bound of traversal stack entries
     float inflate = 0.f;        // outward padding applied to every box
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};
     double sah_cost = 0.0;
     double build_seconds = 0.0;
+    uint64_t spatial_splits = 0;   // nodes split by a plane instead of by object partition
 };
 
-// Builds a binned-SAH binary BVH (multi-threaded), collapses it to 4-wide.
+struct BvhOptions {
+    // spatial splits (SBVH) are evaluated where the children of the best object split overlap by more than
+    // sbvh_alpha x the root's surface area; < 0 switches them off (plain binned SAH)
+    float sbvh_alpha = 1e-5f;
+    // spatial splits may add at most ref_budget x (number of faces) references (leaf triangle records)
+    float ref_budget = 1.0f;
+};
+
+// Builds a binned-SAH binary BVH with spatial splits (multi-threaded), collapses it to 4-wide.
 // Returns false and sets err on invalid input.
 bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
-                const uint32_t* face_object, Bvh4& out, std::string& err, int n_threads = 0);
+                const uint32_t* face_object, Bvh4& out, std::string& err, int n_threads = 0,
+                const BvhOptions* options = nullptr);
 
 }  // namespace rr

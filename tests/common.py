@@ -9,24 +9,11 @@ from radarays_ros_amd import beams, params, scenes
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_beams(n):
-    """Committed beam-sample fixture (seed 42, KAIST preset: 10 deg, D3, p=0.8)."""
-    d = np.load(os.path.join(GOLDEN, "beam_dirs_seed42_n1000.npy"))
-    assert d.shape == (1000, 3) and d.dtype == np.float32
-    return np.ascontiguousarray(d[:n])
+from radarays_ros_amd.fixtures import golden_beams, materials_for  # noqa: E402,F401  (shared with bench.py / tools)
 
 
 def mats_tuple(mats):
     return [m.astuple() for m in mats]
-
-
-def materials_for(scene):
-    if "_pertri" in scene.get("name", ""):
-        return params.config5_materials()
-    m = params.kaist_materials()
-    if max(scene["object_materials"]) >= 2:
-        m = m + [params.PENETRABLE]
-    return m
 
 
 def image_diff(a_f32, b_f32, a_u8, b_u8):

@@ -21,4 +21,4 @@ def test_bvh_builder_invariants_under_asan(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr
-    assert r.stdout.count(": ok") == 9
+    assert r.stdout.count(": ok") == 12

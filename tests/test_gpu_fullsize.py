@@ -27,7 +27,9 @@ def test_target_config_properties(big, native_lib):
     c.set_beam_samples(golden_beams(200))
     pose = scenes.default_pose(s["name"])
     info = c.bvh_info()
-    assert info["n_tris"] == len(s["faces"]) == 10248350
+    assert len(s["faces"]) == 10248350
+    # leaf triangle records: one per face + the parts spatial splits cut (bounded by the builder's reference budget)
+    assert len(s["faces"]) <= info["n_tris"] <= 2 * len(s["faces"]) + 16
     full, _, st = c.simulate(pose)
     assert st["overflow"] == 0
     # closed scene: every pass-0 wave hits; counts are ordered

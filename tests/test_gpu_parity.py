@@ -81,7 +81,7 @@ def test_trace_is_bit_exact_vs_brute_force(native_lib, oracle):
             assert t[i] == np.float32(r[0]) and face[i] == r[1]
     assert hits > 500
     info = c.bvh_info()
-    assert info["n_tris"] == n and info["depth"] >= 3
+    assert n <= info["n_tris"] <= 2 * n + 16 and info["depth"] >= 3   # faces + the parts cut by spatial splits
     c.close()
 
 

@@ -1,7 +1,7 @@
 import sys, time, numpy as np, torch
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
-from common import golden_beams, materials_for
+from radarays_ros_amd.fixtures import golden_beams, materials_for
 cid = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 npass = int(sys.argv[2]) if len(sys.argv) > 2 else (1 if cid == 2 else 4)
 noise = int(sys.argv[3]) if len(sys.argv) > 3 else 2

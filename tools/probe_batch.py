@@ -1,7 +1,7 @@
 import sys, time, os, numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
-from common import golden_beams, materials_for
+from radarays_ros_amd.fixtures import golden_beams, materials_for
 F = int(sys.argv[1]); K = int(sys.argv[2])
 s = scenes.config_scene(2)
 cfg = params.kaist_preset(n_reflections=1, ambient_noise=2)

@@ -4,7 +4,7 @@ import sys, os, time, numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
 from radarays_ros_amd.dist import AzimuthShard
-from common import golden_beams, materials_for
+from radarays_ros_amd.fixtures import golden_beams, materials_for
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cid = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 npass = 1 if cid == 2 else 4

@@ -1,0 +1,170 @@
+// tools/treeq.cpp -- BVH-quality study WITHOUT a GPU: builds the BVH4 with the product's host builder
+// (csrc/rr_bvh.cpp) and walks it with the stepping rule of the HIP kernel (rr_kernels.hip traverse():
+// nearest hit child first, the others pushed far-first, culled by t*(1+1e-4)+1e-3 at test time only) for a
+// logged set of rays; prints node / leaf visits per ray, an estimate of the wave iterations (16 rays per
+// wave, a wave runs as long as its slowest ray) and the algorithmic bytes per ray.
+//
+//   python tools/treeq_dump.py <config id> <passes> <out dir>     (scene + rays: the oracle's ORC_RAYLOG)
+//   g++ -O2 -std=c++17 -ffp-contract=off -I radarays_ros_amd/csrc tools/treeq.cpp radarays_ros_amd/csrc/rr_bvh.cpp -o /tmp/treeq -lpthread
+//   RR_BVH_ALPHA=1e-5 RR_BVH_BUDGET=1 /tmp/treeq <out dir>
+#include "rr_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace rr;
+
+template <typename T>
+static std::vector<T> slurp(const std::string& path)
+{
+    std::vector<T> v;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    v.resize((size_t)n / sizeof(T));
+    if (fread(v.data(), sizeof(T), v.size(), f) != v.size()) { fprintf(stderr, "short read %s\n", path.c_str()); exit(2); }
+    fclose(f);
+    return v;
+}
+
+struct RayRec { int32_t az, pass; float o[3], d[3]; };
+struct Cost { unsigned nodes = 0, leaves = 0, tris = 0; float t = -1.f; uint32_t face = 0xFFFFFFFFu; };
+
+static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range_max)
+{
+    Cost c;
+    float inv[3], oo[3];
+    for (int k = 0; k < 3; k++) {
+        float dk = d[k];
+        if (std::fabs(dk) < 1e-20f) dk = std::copysign(1e-20f, dk);
+        inv[k] = 1.0f / dk; oo[k] = -o[k] * inv[k];
+    }
+    uint32_t stack[256]; int sp = 0;
+    uint32_t cur = 0;
+    float best_t = INFINITY; uint32_t best_face = 0xFFFFFFFFu;
+    float tcull = range_max * 1.0001f + 1e-3f;
+    while (true) {
+        if (!(cur & kLeafFlag)) {
+            c.nodes++;
+            const Node4& n = B.nodes[cur];
+            uint32_t key[4]; uint32_t ref[4]; int nh = 0;
+            for (int q = 0; q < 4; q++) {
+                const Child4& ch = n.c[q];
+                float tn = 0.f, tf = INFINITY;
+                for (int k = 0; k < 3; k++) {
+                    const float a = std::fma(ch.lo[k], inv[k], oo[k]), b = std::fma(ch.hi[k], inv[k], oo[k]);
+                    tn = std::max(tn, std::min(a, b)); tf = std::min(tf, std::max(a, b));
+                }
+                tf *= 1.0000004f;
+                if (tn <= std::min(tf, tcull) && ch.ref != kEmptyRef) {
+                    uint32_t bits; memcpy(&bits, &tn, 4);
+                    key[nh] = (bits & ~3u) | (uint32_t)q; ref[nh] = ch.ref; nh++;
+                }
+            }
+            if (nh > 0) {
+                // sort ascending by key
+                for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); }
+                for (int i = nh - 1; i >= 1; i--) stack[sp++] = ref[i];
+                cur = ref[0];
+                continue;
+            }
+        } else {
+            c.leaves++;
+            const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++) {
+                c.tris++;
+                const TriRec& T = B.tris[first + i];
+                const float* v0 = T.v0; const float* e1 = T.e1; const float* e2 = T.e2;
+                const float pv[3] = { d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0] };
+                const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+                const float invd = 1.0f / det;
+                const float tv[3] = { o[0] - v0[0], o[1] - v0[1], o[2] - v0[2] };
+                const float u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * invd;
+                const float qv[3] = { tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0] };
+                const float v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * invd;
+                const float tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * invd;
+                const bool ok = det != 0.0f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && tt > 0.0f && tt <= range_max;
+                if (ok && (tt < best_t || (tt == best_t && T.face < best_face))) {
+                    best_t = tt; best_face = T.face; tcull = std::fma(tt, 1.0001f, 1e-3f);
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    if (best_face != 0xFFFFFFFFu) { c.t = best_t; c.face = best_face; }
+    return c;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: treeq <dir with verts.f32 faces.u32 rays.bin> [threads]\n"); return 2; }
+    const std::string dir = argv[1];
+    const int threads = argc > 2 ? atoi(argv[2]) : 0;
+    const auto verts = slurp<float>(dir + "/verts.f32");
+    const auto faces = slurp<uint32_t>(dir + "/faces.u32");
+    const auto rays = slurp<RayRec>(dir + "/rays.bin");
+    printf("scene: %zu vertices, %zu faces; %zu rays\n", verts.size() / 3, faces.size() / 3, rays.size());
+
+    Bvh4 B; std::string err;
+    if (!build_bvh4(verts.data(), verts.size() / 3, faces.data(), faces.size() / 3, nullptr, B, err, threads)) {
+        fprintf(stderr, "build failed: %s\n", err.c_str()); return 1;
+    }
+    printf("bvh4: %zu nodes, %zu leaf triangle records (x%.3f), depth %u, stack %u, spatial splits %llu, sah %.2f, build %.2f s\n",
+           B.nodes.size(), B.tris.size(), (double)B.tris.size() / (faces.size() / 3), B.depth, B.stack_need,
+           (unsigned long long)B.spatial_splits, B.sah_cost, B.build_seconds);
+
+    // optional cross-check of the hits against a reference file written by an earlier run
+    std::vector<uint32_t> ref_face; std::vector<float> ref_t;
+    if (FILE* f = fopen((dir + "/hits.ref").c_str(), "rb")) {
+        fclose(f);
+        const auto raw = slurp<uint32_t>(dir + "/hits.ref");
+        ref_face.assign(raw.begin(), raw.begin() + raw.size() / 2);
+        ref_t.resize(raw.size() / 2); memcpy(ref_t.data(), raw.data() + raw.size() / 2, ref_t.size() * 4);
+    }
+
+    std::vector<Cost> cost(rays.size());
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long i = 0; i < (long)rays.size(); i++) cost[i] = trace(B, rays[i].o, rays[i].d, 1000.0f);
+
+    size_t mism = 0;
+    if (ref_face.size() == rays.size()) {
+        for (size_t i = 0; i < rays.size(); i++) if (ref_face[i] != cost[i].face || ref_t[i] != cost[i].t) mism++;
+        printf("hits vs hits.ref: %zu mismatches of %zu\n", mism, rays.size());
+    } else {
+        std::vector<uint32_t> raw(2 * rays.size());
+        for (size_t i = 0; i < rays.size(); i++) { raw[i] = cost[i].face; memcpy(&raw[rays.size() + i], &cost[i].t, 4); }
+        FILE* f = fopen((dir + "/hits.ref").c_str(), "wb"); fwrite(raw.data(), 4, raw.size(), f); fclose(f);
+        printf("wrote hits.ref\n");
+    }
+
+    // per pass: means per ray; wave estimate: 16 consecutive rays of one (azimuth, pass) per wave
+    std::map<int, std::vector<size_t>> by_pass;
+    for (size_t i = 0; i < rays.size(); i++) by_pass[rays[i].pass].push_back(i);
+    double tn = 0, tl = 0, tt = 0, tw = 0; size_t tr = 0, twv = 0;
+    for (auto& kv : by_pass) {
+        double n = 0, l = 0, t = 0, wave_steps = 0; size_t waves = 0;
+        const auto& idx = kv.second;
+        for (size_t k = 0; k < idx.size(); k += 16) {
+            unsigned mx = 0; int az = rays[idx[k]].az;
+            size_t e = k;
+            for (; e < std::min(idx.size(), k + 16) && rays[idx[e]].az == az; e++) mx = std::max(mx, cost[idx[e]].nodes + cost[idx[e]].leaves);
+            wave_steps += mx; waves++;
+            if (e < k + 16 && e < idx.size()) k = e - 16;   // azimuth boundary: next wave starts at e
+        }
+        for (size_t i : idx) { n += cost[i].nodes; l += cost[i].leaves; t += cost[i].tris; }
+        const double m = (double)idx.size();
+        printf("pass %d: %8zu rays  nodes/ray %6.2f  leaves/ray %5.2f  tris/ray %6.2f  steps/ray %6.2f  wave iterations (est.) %6.2f  bytes/ray %7.1f\n",
+               kv.first, idx.size(), n / m, l / m, t / m, (n + l) / m, wave_steps / waves, (n * 128 + t * 48) / m + 132);
+        tn += n; tl += l; tt += t; tr += idx.size(); tw += wave_steps; twv += waves;
+    }
+    printf("all   : %8zu rays  nodes/ray %6.2f  leaves/ray %5.2f  tris/ray %6.2f  steps/ray %6.2f  wave iterations (est.) %6.2f  bytes/ray %7.1f\n",
+           tr, tn / tr, tl / tr, tt / tr, (tn + tl) / tr, tw / twv, (tn * 128 + tt * 48) / tr + 132);
+    return mism ? 1 : 0;
+}
