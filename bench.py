@@ -4,25 +4,40 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-A step = one batch of `--frames-per-rank` (default 8) poses per GPU, each rendered to one polar
-image (400 azimuths x 3424 range bins, mono8) of the workload BASELINE.json's metric is
-quoted on (configs[1]): 400 azimuths x 200 rays, 1 ray-cast pass, 100k-triangle synthetic mesh, KAIST parameter preset (cfg/mulran_kaist_dyncfg.yaml)
-including the Perlin ambient-noise stage with injected per-column offsets.  Mesh, BVH,
-parameters and beam samples are resident in HBM before the timed region; poses are 7
-floats passed as kernel arguments; the image stays in HBM.
+Workload (default): the configuration BASELINE.json's north_star target is quoted on --
+400 azimuths x 3424 range bins, 200 rays per beam, 4 ray-cast passes (Snell/Fresnel split), 10M-triangle
+synthetic mesh, KAIST parameter preset (cfg/mulran_kaist_dyncfg.yaml) including the Perlin ambient-noise stage
+with injected per-column offsets (fresh row per frame).  `--workload` selects the other BASELINE configs.
 
-N > 1 (north_star): the 400 azimuth columns of EVERY frame are sharded over the ranks
-(400/N columns each) and assembled by ONE RCCL collective over xGMI per step
-(default, "scaling": "weak"): a step renders N*F frames; rank r simulates its 400/N-column
-block of all of them in one set of launches and ONE all_to_all_single (the per-frame
-gathers fused) hands frames d*F.. to rank d -- per-GPU work per step is constant,
-value = N*F*K/t.
-`--strong`: one frame per step + one all-gather (latency mode).
+A step = ONE pass over the 16-pose trajectory: every GPU finishes 16 polar images per step, rendered as two
+batches of 8 poses (one set of launches each; `--frames-per-rank` poses per batch, `--batches-per-step` batches),
+batches in flight on 4 streams.  Mesh, BVH, parameters and beam samples are resident in HBM before the timed
+region; poses are 7 floats passed as kernel arguments.  Timing bracket = the reference's stopwatch
+(RadarCPU.cpp:147-148 -> :550).
 
-Extra objects on the JSON line: "roofline" (dominant kernel = k_trace, hipEvent-timed on
-its launch stream inside the timed region) and, at N = 1 on rank 0, "cpu_baseline" (the
-CPU oracle = line-faithful port of RadarCPU::simulate, OpenMP over azimuths like
-RadarCPU.cpp:155, timed on a bounded sample of the same workload).
+`value`: images left in HBM ("inputs resident, output resident": the bench contract).  Because the reference's
+simulate() ends with the image in HOST memory (m_polar_image, RadarCPU.cpp:542,555-561), the same line carries
+`host_resident`: the same K steps timed THROUGH the last D2H copy of every image into page-locked host memory
+(rr_simulate_batch_host_async: copy stream, overlapped with the next batch), and `single_pose`: one pose per
+launch set (the latency-oriented shape a live ROS node would use).  Before every timed region the GPU is
+pre-warmed by wall time (>= 0.3 s of steps, untimed) so that `--steps 20` reads sustained clocks.
+
+N > 1 (north_star): the 400 azimuth columns of EVERY frame are sharded over the ranks (400/N columns each) and
+assembled by ONE RCCL collective over xGMI per batch (default, "scaling": "weak"): a batch renders N*F frames;
+rank r simulates its 400/N-column block of all of them in one set of launches and ONE all_to_all_single (the
+per-frame gathers fused) hands frames d*F.. to rank d -- per-GPU work per step is constant, value = N*16*K/t.
+`--strong`: one frame per batch + one all-gather (latency mode).
+
+Extra objects on the JSON line:
+  "roofline"     the kernel that takes the most GPU time (picked from the measured per-kernel times, normally the
+                 later-pass k_trace) against the bound that really limits it: VALU instruction issue.
+                 achieved = wave-instructions/s = SQ_INSTS_VALU per launch (rocprofv3 PMC of this same command,
+                 profiles/roofline_counters.json) / the launch duration measured live in THIS run (hipExtLaunchKernel
+                 begin/end events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64
+                 VALU instruction (SIMD-32) = 1.2288 T/s.  HBM traffic (PMC) and the algorithmic byte rate are
+                 secondary keys -- the tree is served by L1/L2, HBM runs at a few percent of its peak.
+  "cpu_baseline" (N = 1, rank 0) the CPU oracle = line-faithful port of RadarCPU::simulate, OpenMP over azimuths
+                 like RadarCPU.cpp:155, timed on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -37,6 +52,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# MI355X_MICROARCH.md "Wave scheduling": 4 SIMD-32 per CU, a wave64 VALU instruction issues over 2 cycles
+VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 2.0
+PREWARM_S = 0.3
 
 
 def algorithmic_bytes_per_wave_pass(n_tris):
@@ -57,22 +75,31 @@ WORKLOADS = {
     # checkout, so this one config is parity-unpinned); run with --frames-per-rank 1
     "config5_10M_400x1000_8pass_pertri": (5, 8, 1000),
 }
+KERNEL_LABEL = {"trace0": "k_trace<FIRST> (pass 0)", "trace": "k_trace (passes 1..P-1)", "shade": "k_shade",
+                "scan": "k_scan", "column": "k_column", "assemble": "k_assemble_u8x4"}
+
+
+def pct(v, q):
+    v = np.sort(np.asarray(v, np.float64))
+    return float(v[min(len(v) - 1, int(q * len(v)))]) if len(v) else 0.0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--workload", default="config2_100k_400x200_1pass", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="target_10M_400x200_4pass", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host_resident / single_pose regions")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--ambient-noise", type=int, default=2)
-    ap.add_argument("--strong", action="store_true", help="N>1: one frame per step + all-gather")
+    ap.add_argument("--strong", action="store_true", help="N>1: one frame per batch + all-gather")
     ap.add_argument("--force-slots", action="store_true", help="run the N>1 step loop (with its collective) on one rank (debug)")
-    ap.add_argument("--slots", type=int, default=4, help="steps in flight (streams + buffer sets); RR_LANES must be >= slots")
+    ap.add_argument("--slots", type=int, default=4, help="batches in flight (streams + buffer sets); RR_LANES must be >= slots")
     ap.add_argument("--frames-per-rank", type=int, default=8,
-                    help="frames each GPU finishes per step (one set of launches); a step = N x this many frames")
+                    help="frames each GPU finishes per batch (one set of launches); a batch = N x this many frames")
+    ap.add_argument("--batches-per-step", type=int, default=2, help="batches per step (default: 2 x 8 = the 16-pose trajectory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +131,7 @@ def main():
     cfg = params.kaist_preset(n_reflections=n_pass, n_samples=n_rays, ambient_noise=args.ambient_noise)
     mats = materials_for(scene)
     beams = golden_beams(n_rays)
-    # fresh offsets per frame of a step like the reference draws them (RadarCPU.cpp:461-472): 16 rows, frame f -> row f % 16
+    # fresh offsets per frame of a batch like the reference draws them (RadarCPU.cpp:461-472): 16 rows, frame f -> row f % 16
     noise = (np.random.RandomState(7).uniform(0, 1, 16 * params.N_ANGLES) * 1000.0).astype(np.float32)
     poses = scenes.trajectory(16, scene["name"])
 
@@ -116,81 +143,186 @@ def main():
     ctx.set_noise_offsets(noise)
     n_tris = len(scene["faces"])
 
-    shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, torch.device("cuda", local_rank),
+    dev = torch.device("cuda", local_rank)
+    shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, dev,
                          force_collective=args.force_slots, strong=args.strong,
                          frames_per_rank=args.frames_per_rank, n_slots=args.slots)
-    fps = shard.frames_per_step
-    stream = torch.cuda.current_stream()
+    fpb = shard.frames_per_step                 # frames of one batch (all ranks)
+    bps = max(1, args.batches_per_step)
+    fps = fpb * bps                             # frames per step (all ranks)
 
-    def step(k):
-        shard.step([poses[(k * fps + f) % len(poses)] for f in range(fps)], stream)
+    def step(k, done=None):
+        for b in range(bps):
+            shard.step([poses[((k * bps + b) * fpb + f) % len(poses)] for f in range(fpb)], None,
+                       done_event=done if b == bps - 1 else None)
+
+    def prewarm(fn, seconds=PREWARM_S):
+        """untimed: at least `seconds` of steps so the timed region starts at sustained clocks"""
+        t0, k = time.perf_counter(), 0
+        while True:
+            fn(k); k += 1
+            if k % 4 == 0:
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 >= seconds:
+                    return k
 
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
     # ---- instrumentation, all of it outside (and before) the timed region ---------------------------------
-    # one step: wave-pass count of this workload
-    step(0)
+    # one batch: wave-pass count of this workload
+    shard.step([poses[f % len(poses)] for f in range(fpb)], None)
     torch.cuda.synchronize()
     st = ctx.stats()
-    wave_passes_frame_rank = st["wave_passes"]
+    wave_passes_batch_rank = st["wave_passes"]
     assert st["overflow"] == 0, st
-    # one step with the counting build of k_trace: measured node / triangle fetches per wave-pass
+    # one batch with the counting build of k_trace: measured node / triangle fetches per wave-pass
     ctx.set_stats_mode(True)
-    step(0)
+    shard.step([poses[f % len(poses)] for f in range(fpb)], None)
     torch.cuda.synchronize()
     st2 = ctx.stats()
     ctx.set_stats_mode(False)
-    # k_trace alone on the GPU (one step at a time, nothing else in flight): the kernel's own speed, as
-    # opposed to its duration while 4 steps share the chip in the timed region below
-    ctx.set_timing_mode(2)
-    ctx.kernel_time("trace", reset=True)
-    for k in range(12):
-        step(k)
+    # every kernel alone on the GPU (one batch at a time, nothing else in flight): which kernel takes the most
+    # time, and its own speed -- as opposed to its duration while several batches share the chip below
+    prewarm(step)
+    ctx.reserve_timing_events(4096)
+    ctx.set_timing_mode(1)
+    for name in KERNEL_LABEL:
+        ctx.kernel_time(name, reset=True)
+    for k in range(6):
+        shard.step([poses[(k * fpb + f) % len(poses)] for f in range(fpb)], None)
         torch.cuda.synchronize()
-    iso_ms, iso_launches = ctx.kernel_time("trace", reset=True)
-
+    iso = {name: ctx.kernel_time(name, reset=True) for name in KERNEL_LABEL}      # (total ms, launches)
+    ctx.set_timing_mode(0)
+    dominant = max(iso, key=lambda n: iso[n][0])
     # ---- the timed region: exactly `steps` steps between two synchronisation points ------------------------
-    # (timing mode 2 stays on: hipEvents around k_trace only, on the launch stream)
+    # (timing mode 2: pooled hipExtLaunchKernel events around the k_trace launches only, on the launch stream)
+    done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ctx.reserve_timing_events(2 * n_pass * bps * args.steps + 64)
+    prewarm(step)
+    ctx.set_timing_mode(2)
+    ctx.kernel_time("trace", reset=True); ctx.kernel_time("trace0", reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    done[0].record(torch.cuda.current_stream())
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        step(k, done[k + 1])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    trace_ms, trace_launches = ctx.kernel_time("trace", reset=True)
+    live = {n: ctx.kernel_time(n, reset=True) for n in ("trace", "trace0")}
     ctx.set_timing_mode(0)
+    # per-step periods: completion of step k-1 -> completion of step k (steps overlap, so this is the cadence)
+    periods_ms = [done[k].elapsed_time(done[k + 1]) for k in range(1, args.steps)]
 
     elapsed = t1 - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        wp = torch.tensor([wave_passes_frame_rank], dtype=torch.int64, device="cuda")
+        wp = torch.tensor([wave_passes_batch_rank], dtype=torch.int64, device="cuda")
         dist.all_reduce(wp, op=dist.ReduceOp.SUM)
-        wave_passes_frame = int(wp.item())
+        wave_passes_batch = int(wp.item())
     else:
-        wave_passes_frame = wave_passes_frame_rank
+        wave_passes_batch = wave_passes_batch_rank
+
+    # ---- N = 1 extras: the image delivered to host memory; one pose per launch set ---------------------------
+    host_res = single = None
+    if world == 1 and not args.no_extras and not args.force_slots:
+        npx = cfg.n_cells * params.N_ANGLES
+        F = args.frames_per_rank
+        streams = [torch.cuda.Stream(device=dev) for _ in range(args.slots)]
+        hosts = [native.HostImages((F, cfg.n_cells, params.N_ANGLES)) for _ in range(args.slots)]
+        state = {"n": 0}
+
+        def step_host(k):
+            for b in range(bps):
+                i = state["n"] % args.slots
+                state["n"] += 1
+                ctx.wait_host(hosts[i].ptr)           # the consumer is done with this buffer (nothing to do here)
+                ctx.simulate_batch_host_async([poses[((k * bps + b) * F + f) % len(poses)] for f in range(F)],
+                                              hosts[i].ptr, streams[i].cuda_stream)
+        prewarm(step_host)
+        ctx.wait_host(None); torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for k in range(args.steps):
+            step_host(k)
+        ctx.wait_host(None)                           # through the last D2H copy
+        torch.cuda.synchronize()
+        th1 = time.perf_counter()
+        host_res = {"value": round(args.steps * bps * F / (th1 - th0), 2), "unit": "images/s",
+                    "ms_per_step": round(1e3 * (th1 - th0) / args.steps, 4),
+                    "what": "same steps, every mono8 image copied to page-locked host memory on a copy stream "
+                            "(rr_simulate_batch_host_async), timed through the last copy",
+                    "d2h_GBps": round(args.steps * bps * F * npx / (th1 - th0) / 1e9, 3)}
+        for h in hosts:
+            h.close()
+        one = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, 0, 1, dev, frames_per_rank=1, n_slots=args.slots)
+        n1 = max(args.steps, 16)
+        prewarm(lambda k: one.step([poses[k % len(poses)]], None))
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for k in range(n1):
+            one.step([poses[k % len(poses)]], None)
+        torch.cuda.synchronize()
+        ts1 = time.perf_counter()
+        single = {"value": round(n1 / (ts1 - ts0), 2), "unit": "images/s", "frames_per_launch_set": 1,
+                  "ms_per_image": round(1e3 * (ts1 - ts0) / n1, 4), "images": n1,
+                  "what": "one pose per set of launches, %d in flight on %d streams, image left in HBM" % (args.slots, args.slots)}
+        one.close()
 
     out = None
     if rank == 0:
         img_per_s = args.steps * fps / elapsed
         b_wp = algorithmic_bytes_per_wave_pass(n_tris)
-        launches_per_frame = max(1, n_pass)
-        avg_trace_s = (trace_ms / max(trace_launches, 1)) * 1e-3
-        bytes_per_launch = wave_passes_frame_rank / launches_per_frame * b_wp      # one step of this rank
-        achieved = bytes_per_launch / avg_trace_s / 1e9 if avg_trace_s > 0 else 0.0
-        iso_us = 1e3 * iso_ms / max(iso_launches, 1)
         wp2 = max(int(st2["wave_passes"]), 1)
         measured_b_wp = (st2["nodes_visited"] * 128 + st2["tris_tested"] * 48) / wp2 + 132
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(args.workload, {}).get("k_trace_hbm_bytes_per_launch")
+        # --- roofline of the dominant kernel ------------------------------------------------------------------
+        counters = {}
+        cf = os.path.join(ROOT, "profiles", "roofline_counters.json")
+        if os.path.exists(cf):
+            counters = json.load(open(cf)).get(args.workload, {})
+        kc = counters.get("kernels", {}).get(dominant, {})
+        insts = kc.get("SQ_INSTS_VALU")                     # wave-instructions per launch (PMC, same command)
+        traffic = kc.get("hbm_bytes")
+        iso_ms, iso_n = iso[dominant]
+        iso_s = 1e-3 * iso_ms / max(iso_n, 1)
+        if dominant in live and live[dominant][1] > 0:
+            live_s = 1e-3 * live[dominant][0] / live[dominant][1]
+            live_n = int(live[dominant][1])
+        else:                                               # a kernel other than k_trace dominates: isolated figure only
+            live_s, live_n = iso_s, int(iso_n)
+        n_launch_frames = fpb // world                      # frames one launch of this rank covers
+        wp_launch = wave_passes_batch_rank / max(n_pass, 1)  # mean wave-passes of one k_trace launch
+        achieved = (insts / live_s) if (insts and live_s > 0) else None
+        roof = {"bound": "valu_issue", "kernel": KERNEL_LABEL[dominant],
+                "achieved": None if achieved is None else round(achieved / 1e9, 2),
+                "peak": round(VALU_PEAK_WAVE_INSTR_S / 1e9, 1), "unit": "G wave-instr/s",
+                "frac": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTR_S, 4),
+                "traffic": traffic,
+                "avg_launch_us": round(live_s * 1e6, 2), "launches": live_n, "batches_in_flight": int(args.slots),
+                "wave_instr_per_launch": insts,
+                "basis": "SQ_INSTS_VALU per launch (rocprofv3 --pmc of this command: %s) / average launch duration of the "
+                         "timed region (hipExtLaunchKernel begin/end events on the launch stream); unweighted: k_trace "
+                         "issues no f64 and one transcendental (v_rcp_f32) per leaf step; peak = 1024 SIMD-32 x 2.4 GHz / 2 "
+                         "cycles per wave64 instruction" % counters.get("source", "profiles/roofline_counters.json missing"),
+                "isolated": {"avg_launch_us": round(iso_s * 1e6, 2),
+                             "achieved": None if not insts or iso_s <= 0 else round(insts / iso_s / 1e9, 2),
+                             "frac": None if not insts or iso_s <= 0 else round(insts / iso_s / VALU_PEAK_WAVE_INSTR_S, 4),
+                             "what": "the same launches with ONE batch on the GPU at a time"},
+                "kernel_time_share_isolated": {KERNEL_LABEL[n]: round(iso[n][0] / max(sum(v[0] for v in iso.values()), 1e-9), 4) for n in iso},
+                # secondary views (never `frac`): what crosses the HBM interface, and the SURVEY §8d algorithmic byte rate
+                "hbm_measured": (None if not traffic or live_s <= 0 else
+                                 {"GBps": round(traffic / live_s / 1e9, 2), "of_peak": round(traffic / live_s / 1e9 / HBM_PEAK_GBS, 5),
+                                  "peak_GBps": HBM_PEAK_GBS,
+                                  "source": "2 x FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes (profiles/roofline_counters.json)"}),
+                "algorithmic_bytes_per_wave_pass": b_wp,
+                "measured_bytes_per_wave_pass": round(measured_b_wp, 1),
+                "algorithmic_GBps": (round(wp_launch * b_wp / live_s / 1e9, 2) if dominant in ("trace", "trace0") and live_s > 0 else None),
+                "frames_per_launch": n_launch_frames}
         out = {
             "metric": "polar images/sec (400 az x 3424 bins)",
             "value": round(img_per_s, 2),
@@ -205,36 +337,21 @@ def main():
             "config": {"workload": args.workload, "triangles": int(n_tris), "azimuths": params.N_ANGLES,
                        "range_bins": int(cfg.n_cells), "rays_per_beam": n_rays, "passes": n_pass,
                        "ambient_noise": int(cfg.ambient_noise),
-                       "frames_per_step": fps,
+                       "frames_per_step": fps, "frames_per_batch": fpb, "batches_per_step": bps,
+                       "images": "resident in HBM",
                        "sharding": ("single GPU" if world == 1 else
-                                    "azimuth columns x%d, 1 frame/step + 1 all-gather" % world if args.strong else
-                                    "azimuth columns x%d, %d frames/step, 1 all_to_all/step (frame f -> rank f)" % (world, fps))},
-            "rays_per_s": round(wave_passes_frame / fps * img_per_s, 1),
-            "wave_passes_per_frame": int(wave_passes_frame // fps),
-            # `achieved` / `frac` follow the bench contract: ALGORITHMIC bytes (SURVEY §8d floor: every node and
-            # triangle a ray needs, as if each came from HBM) / the launch time.  They are NOT the HBM
-            # utilisation: the tree is shared by all rays and served by L1/L2, so the bytes that really
-            # cross the HBM interface (`traffic`, PMC) are far fewer -- `hbm_measured` is that figure, and
-            # `limiter` names what actually bounds the kernel.
-            "roofline": {"bound": "hbm", "kernel": "k_trace",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "achieved_basis": "algorithmic bytes per launch / avg launch time (not HBM utilisation)",
-                         "hbm_measured": (None if not traffic or avg_trace_s <= 0 else
-                                          {"GBps": round(traffic / avg_trace_s / 1e9, 2),
-                                           "frac": round(traffic / avg_trace_s / 1e9 / HBM_PEAK_GBS, 5),
-                                           "traffic_over_algorithmic": round(traffic / max(bytes_per_launch, 1.0), 4),
-                                           "source": "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}),
-                         "limiter": "VALU issue + dependent-fetch latency; node/triangle fetches hit L1/L2 (tree is cache resident)",
-                         "algorithmic_bytes_per_wave_pass": b_wp,
-                         # SURVEY §8d "reported figure": measured visits of THIS BVH4 (128-B nodes, 48-B triangles)
-                         "measured_bytes_per_wave_pass": round(measured_b_wp, 1),
-                         "achieved_measured": round(achieved * measured_b_wp / b_wp, 2),
-                         "avg_launch_us": round(avg_trace_s * 1e6, 2), "launches": int(trace_launches),
-                         "steps_in_flight": int(args.slots),
-                         "isolated": {"avg_launch_us": round(iso_us, 2),
-                                      "achieved": round(bytes_per_launch / (iso_us * 1e-6) / 1e9, 2) if iso_us > 0 else None,
-                                      "frac": round(bytes_per_launch / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if iso_us > 0 else None}},
+                                    "azimuth columns x%d, 1 frame/batch + 1 all-gather" % world if args.strong else
+                                    "azimuth columns x%d, %d frames/batch, 1 all_to_all/batch (frame f -> rank f)" % (world, fpb))},
+            "rays_per_s": round(wave_passes_batch / fpb * img_per_s, 1),
+            "wave_passes_per_frame": int(wave_passes_batch // fpb),
+            "images_per_s_per_step": {"median": round(fps / (1e-3 * pct(periods_ms, 0.5)), 2) if periods_ms else None,
+                                      "p10": round(fps / (1e-3 * pct(periods_ms, 0.9)), 2) if periods_ms else None,
+                                      "p90": round(fps / (1e-3 * pct(periods_ms, 0.1)), 2) if periods_ms else None,
+                                      "basis": "completion-to-completion period of consecutive steps (hip events)"},
+            "prewarm_s": PREWARM_S,
+            "host_resident": host_res,
+            "single_pose": single,
+            "roofline": roof,
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -284,6 +401,8 @@ def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
             break
     med = float(np.median(secs))
     return {"value": round(1.0 / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "p10": round(1.0 / pct(secs, 0.9), 3), "p90": round(1.0 / pct(secs, 0.1), 3),
+            "embree": "unavailable",        # no Embree (nor rmagine) on this box: the in-repo SAH BVH2 stands in
             "sample": "%d full frames of the same workload (16-pose trajectory), median of the "
                       "RadarCPU.cpp:147-550 stopwatch bracket, OpenMP over azimuths, in-repo SAH BVH2 "
                       "(Embree absent); threads = fastest of %s on this %d-thread host" % (frames, cands, ncpu)}

@@ -10,7 +10,8 @@
  *  marshals the protected state `simulate()` reads
  * (Radar.hpp:66-105) into the calls below -- plain pointers and sizes only.
  *
- * Threading: one rr_ctx is used by one thread at a time; one ctx per GPU.
+ * Threading: one rr_ctx is used by one thread at a time; one ctx per GPU.  Several GPUs of one node behind ONE
+ * object: rr_multi (below) -- one process, one ctx per device, one RCCL collective per call.
  * Errors: every call returns 0 on success, <0 on error; rr_last_error() gives
  * the text.  No exceptions cross this boundary.  There is NO CPU fallback: if
  * no HIP device is usable rr_create() fails.
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 2
+#define RR_ABI_VERSION 3
 #define RR_MAX_BATCH 64   /* frames (poses or material sets) one call renders in one set of launches */
 
 typedef struct rr_ctx rr_ctx;
@@ -175,6 +176,17 @@ int rr_simulate_batch_columns_device(rr_ctx* ctx, const float* poses, int n_fram
  * from C/C++ (tools/cpp_bench.cpp: 41k images/s at config 2 with 4 poses per call on 4 streams). */
 int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint8_t* d_imgs_u8, void* stream);
 
+/* The reference leaves every frame in HOST memory (m_polar_image -> sensor_msgs::Image, RadarCPU.cpp:542,555-561).
+ * Whole frames of n_frames poses like rr_simulate_batch_device, delivered to the caller's host buffer
+ * h_imgs_u8 = [n_frames][n_cells][n_angles]: kernels on `stream`, then ONE D2H copy on the context's copy stream,
+ * so the copy of a batch overlaps the kernels of the next one.  Returns at once; the images are complete after
+ * rr_wait_host(ctx, h_imgs_u8) (NULL: every outstanding copy) or rr_synchronize().  For a copy that really
+ * overlaps, h_imgs_u8 must be page-locked: rr_host_alloc / rr_host_free (hipHostMalloc). */
+int rr_simulate_batch_host_async(rr_ctx* ctx, const float* poses, int n_frames, uint8_t* h_imgs_u8, void* stream);
+int rr_wait_host(rr_ctx* ctx, const void* h_imgs_u8);
+void* rr_host_alloc(size_t bytes);
+void  rr_host_free(void* p);
+
 /* Assemble the mono8 image from column-major columns, applying scroll_image
  * (RadarCPU.cpp:457): d_img[c][(scroll + a) % n_angles] = d_cols[a][c].
  * Device buffers, asynchronous on `stream`. */
@@ -212,7 +224,8 @@ int rr_assemble_frames_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, 
  * column buffer + rr_assemble_image_device into d_img_u8.  Asynchronous. */
 int rr_simulate_device(rr_ctx* ctx, const float pose_qxyzw_t[7], uint8_t* d_img_u8, void* stream);
 
-/* Blocks until `stream` (NULL = ctx stream) and the ctx's own frame lanes are idle, then reports what
+/* Blocks until `stream` (NULL = ctx stream), the ctx's own frame lanes and copy stream -- and, because batches may
+ * have been issued on further caller streams, everything else on the device -- are idle, then reports what
  * the asynchronous (*_device) entry points could not: -7 if any frame enqueued since the last call
  * exceeded its wave/signal queue capacity, -8 if one met an object/material id outside the tables
  * (such a frame is truncated; the synchronous rr_simulate returns the same codes itself). */
@@ -238,6 +251,41 @@ int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* 
 int rr_set_timing_mode(rr_ctx* ctx, int enable /* 0 off, 1 every kernel, 2 k_trace only */);
 int rr_get_kernel_time(rr_ctx* ctx, const char* kernel /* "trace"|"shade"|"scan"|"column"|"assemble" */,
                        double* total_ms, uint64_t* launches, int reset);
+
+/* every launch duration (ms) recorded for `kernel` since the last reset ("trace0" = pass 0, "trace" = later
+ * passes, ...): *n_out = count, the first min(count, capacity) values go to out_ms (may be NULL). */
+int rr_get_kernel_samples(rr_ctx* ctx, const char* kernel, float* out_ms, size_t capacity, size_t* n_out);
+/* pre-creates n timing events so that a timed region never calls hipEventCreate */
+int rr_reserve_timing_events(rr_ctx* ctx, size_t n);
+
+/* ---- several GPUs of one node behind one object (SURVEY.md §8b "Threading", §8e) -------------------------
+ * The reference creates ONE backend object per process (src/radar_simulator.cpp:145-176) and fans out inside it
+ * (OpenMP over azimuths, RadarCPU.cpp:155).  rr_multi is that object for n GPUs: one rr_ctx per device, mesh and
+ * parameters replicated, device i renders the contiguous azimuth block rr_partition(n_angles, n, i) of every frame
+ * of a call in one set of launches, ONE RCCL collective per call over xGMI brings the blocks to device 0
+ * (ncclAllGather for equal blocks, a group of send/recv pairs for ragged ones), which transposes them into the
+ * mono8 images and copies them to the caller's host buffer.  With one device no collective runs and the images
+ * are byte-identical to rr_simulate's.  RCCL (librccl.so.1) is loaded at run time when n > 1. */
+typedef struct rr_multi rr_multi;
+rr_multi* rr_create_multi(const int* devices, int n_devices);    /* NULL on failure: rr_multi_last_error(NULL) */
+void rr_destroy_multi(rr_multi* m);
+const char* rr_multi_last_error(const rr_multi* m);
+int rr_multi_device_count(const rr_multi* m);
+rr_ctx* rr_multi_ctx(rr_multi* m, int i);                        /* the context of device i (stats, tuning) */
+/* azimuth block [*begin, *end) of `rank` among `world`: contiguous, sizes differ by at most one column */
+void rr_partition(int n_angles, int world, int rank, int* begin, int* end);
+/* replicated setters: same contracts as the rr_set_* calls above, applied to every device */
+int rr_multi_set_mesh(rr_multi* m, const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object_id);
+int rr_multi_set_materials(rr_multi* m, const rr_material* materials, size_t n_materials,
+                           const int32_t* object_materials, size_t n_objects, int32_t material_id_air);
+int rr_multi_set_config(rr_multi* m, const rr_config* cfg);
+int rr_multi_set_beam_samples(rr_multi* m, const float* dirs, size_t n);
+int rr_multi_set_noise_offsets(rr_multi* m, const float* rnd, size_t n);
+int rr_multi_set_motion_poses(rr_multi* m, const float* poses, size_t n);
+/* Radar::simulate on all devices: one frame / n_frames (1..RR_MAX_BATCH) frames, host output
+ * [n_frames][n_cells][n_angles], synchronous; -7 / -8 like rr_simulate when a device reports an overflow / bad id */
+int rr_multi_simulate(rr_multi* m, const float pose_qxyzw_t[7], uint8_t* out_u8);
+int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8_t* out_imgs_u8);
 
 #ifdef __cplusplus
 }

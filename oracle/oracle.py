@@ -49,7 +49,7 @@ class OrcConfig(C.Structure):
 class OrcStats(C.Structure):
     _fields_ = [("wave_passes", C.c_uint64), ("hits", C.c_uint64), ("signals", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("seconds", C.c_double)]
+                ("seconds", C.c_double), ("near_threshold", C.c_uint64)]
 
 
 def build(force=False):

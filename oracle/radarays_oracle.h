@@ -82,6 +82,7 @@ typedef struct {
     uint64_t nodes_visited; /* BVH nodes popped (0 for brute force) */
     uint64_t tris_tested;
     double   seconds;       /* stopwatch bracket of RadarCPU.cpp:147-148 -> :550 */
+    uint64_t near_threshold;/* test bookkeeping: waves whose reflected / refracted energy lies within 1e-6 of the pruning threshold */
 } orc_stats;
 
 typedef struct orc_scene orc_scene;

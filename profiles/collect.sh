@@ -1,20 +1,20 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and HBM PMC passes of
-# the SAME command the driver benches (python bench.py), summaries under gpurun_out/.
-# usage: profiles/collect.sh <round-tag> [bench args...]
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and PMC passes of the SAME command the
+# driver benches (python bench.py; default workload = the north-star target), summaries under gpurun_out/.
+# usage: profiles/collect.sh <round-tag> [bench args...]        e.g.  collect.sh r03_c3 --workload config3_1M_400x200_4pass
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-tag=${1:-r01}; shift
+tag=${1:-r03}; shift
 OUT=$R/gpurun_out/profiles_$tag; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-ARGS="--steps 200 --warmup 20 --no-cpu-baseline $@"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/ktrace.log
+ARGS="--steps 60 --warmup 5 --no-cpu-baseline --no-extras $@"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/ktrace.log
 cp $(find $OUT/ktrace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_$c.log
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_$c.log
 done
-timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $OUT/pmc_cache -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_cache.log
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.log
-timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_lds -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_lds.log
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $OUT/pmc_cache -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_cache.log
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.log
+timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_lds -- python3 $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_lds.log
 python3 - <<PY
 import csv, glob, collections, json
 out = {}

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -56,6 +57,7 @@ struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0.0;
     uint64_t launches = 0;
+    std::vector<float> samples_ms;   // every launch since the last reset (median / percentiles)
 };
 
 }  // namespace
@@ -69,7 +71,7 @@ struct Lane {
     DevBuf<SigRec> d_sigtmp, d_sig;
     DevBuf<float> d_hit_t, d_cols_f32;
     DevBuf<Counters> d_counters;
-    DevBuf<uint32_t> d_sticky;    // error bits of ALL frames since the last rr_synchronize / rr_get_stats (async entry points)
+    DevBuf<uint32_t> d_sticky;    // error bits of ALL frames since the last rr_synchronize (async entry points); the synchronous entry points clear them when they report an error themselves
     DevBuf<uint8_t> d_img_u8;     // host-buffer path: assembled image before the D2H copy
     DevBuf<float> d_img_f32;
     DevBuf<SegStats> d_seg_stats;
@@ -80,6 +82,10 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_consumed = nullptr;
     bool pending_consume = false;
+    // host delivery: the lane's device images are free again when ev_copied has passed
+    hipEvent_t ev_copied = nullptr;
+    bool pending_copy = false;
+    const void* copy_dst = nullptr;
 };
 
 struct rr_ctx {
@@ -132,9 +138,44 @@ struct rr_ctx {
     int stack_lds_max = 64;      // traversal stack entries kept in LDS (RR_STACK_LDS lowers it: tests of the spill path)
     int timing = 0;   // 0 off, 1 every kernel, 2 k_trace only
     std::map<std::string, KernelTimer> timers;
+    // timing events are pooled: created once, handed out in the frame path, returned when rr_get_kernel_time
+    // reads them (no hipEventCreate / hipEventDestroy between the synchronisation points of a timed region)
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t take_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+    }
+
+    // host-image delivery (rr_simulate_batch_host_async): one copy stream for all D2H traffic
+    hipStream_t copy_stream = nullptr;
+    bool roctx = false;
 };
 
 namespace {
+
+// roctx ranges around the enqueue of trace / shade / scan / column / assemble (readable rocprofv3
+// timelines with --marker-trace).  Optional: RR_ROCTX=1 loads librocprofiler-sdk-roctx / libroctx64 at run time.
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+bool roctx_load()
+{
+    static int state = 0;   // 0 untried, 1 ok, -1 missing
+    if (state == 0) {
+        state = -1;
+        for (const char* n : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
+            void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+            g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+            if (g_roctx_push && g_roctx_pop) { state = 1; break; }
+        }
+    }
+    return state == 1;
+}
+inline void roctx_push(const char* name) { if (g_roctx_push) g_roctx_push(name); }
+inline void roctx_pop() { if (g_roctx_pop) g_roctx_pop(); }
 
 int fail(rr_ctx* c, int code, const std::string& msg)
 {
@@ -287,7 +328,9 @@ int upload_tables(rr_ctx* c)
     // one row of n_angles offsets, or k rows: frame f of a batch then takes row f % k (the reference draws
     // fresh offsets for every frame, RadarCPU.cpp:461-472)
     const size_t A = (size_t)g.n_angles;
-    c->noise_rows = (c->noise.size() >= 2 * A && c->noise.size() % A == 0) ? (int)(c->noise.size() / A) : 1;
+    if (!c->noise.empty() && c->noise.size() % A != 0)
+        return fail(c, -3, "rr_set_noise_offsets: the number of offsets must be a multiple of n_angles (one row per frame of a batch)");
+    c->noise_rows = c->noise.size() >= 2 * A ? (int)(c->noise.size() / A) : 1;
     std::vector<float> nz((size_t)c->noise_rows * A, 0.0f);
     for (size_t i = 0; i < nz.size() && i < c->noise.size(); i++) nz[i] = c->noise[i];
     RR_HIP(c, c->d_noise.ensure(nz.size()));
@@ -416,10 +459,12 @@ struct TimedScope {
     bool on;
     TimedScope(rr_ctx* c_, hipStream_t s_, const char* n_) : c(c_), s(s_), name(n_) {
         on = c->timing == 1;
-        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+        if (on) { a = c->take_event(); b = c->take_event(); (void)hipEventRecord(a, s); }
+        if (c->roctx) roctx_push(name);
     }
     ~TimedScope() {
         if (on) { (void)hipEventRecord(b, s); c->timers[name].pending.emplace_back(a, b); }
+        if (c->roctx) roctx_pop();
     }
 };
 
@@ -463,21 +508,23 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     P.n_loc = n_loc; P.n_frames = n_frames;
     if (d_matsets) {   // parameter batch: one pose, one material table per frame
         P.materials = d_matsets; P.mat_stride = mat_stride; P.share_first = 1;
+        P.noise_rows = 1;     // every set is the SAME frame under another material table: one noise realisation (row 0)
         for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[k];
     } else
     for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[7 * f + k];
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
     L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
     for (int pass = 0; pass < g.n_reflections; pass++) {
+        if (c->roctx) roctx_push(pass == 0 ? "trace pass 0" : "trace");
         if (c->timing) {
             // the kernel's own begin/end timestamps (hipExtLaunchKernel events), on its launch stream
-            hipEvent_t a = nullptr, b = nullptr;
-            RR_HIP(c, hipEventCreate(&a)); RR_HIP(c, hipEventCreate(&b));
+            hipEvent_t a = c->take_event(), b = c->take_event();
             launch_trace(P, pass, c->stats_mode, s, a, b);
-            c->timers["trace"].pending.emplace_back(a, b);
+            c->timers[pass == 0 ? "trace0" : "trace"].pending.emplace_back(a, b);
         } else {
             launch_trace(P, pass, c->stats_mode, s);
         }
+        if (c->roctx) roctx_pop();
         { TimedScope t(c, s, "shade"); launch_shade(P, pass, s); }
         if (pass < g.n_reflections - 1) { TimedScope t(c, s, "scan"); launch_scan(P, pass, s); }
     }
@@ -492,6 +539,16 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
 extern "C" {
 
 int rr_abi_version(void) { return RR_ABI_VERSION; }
+
+void rr_partition(int n_angles, int world, int rank, int* begin, int* end)
+{
+    // contiguous azimuth blocks that differ by at most one column (radarays_ros_amd/dist.py: partition)
+    if (world < 1) world = 1;
+    const int base = n_angles / world, rem = n_angles % world;
+    const int b = rank * base + (rank < rem ? rank : rem);
+    if (begin) *begin = b;
+    if (end) *end = b + base + (rank < rem ? 1 : 0);
+}
 
 void rr_default_config(rr_config* cfg)
 {
@@ -540,11 +597,16 @@ rr_ctx* rr_create(int device)
                                                 : std::min(3, n_lanes);
     if (getenv("RR_PASS0_AZ")) { const int a = atoi(getenv("RR_PASS0_AZ")); if (a == 1 || a == 2 || a == 4 || a == 8 || a == 16) c->pass0_az = a; }
     if (getenv("RR_STACK_LDS")) c->stack_lds_max = std::max(1, std::min(64, atoi(getenv("RR_STACK_LDS"))));
+    if (getenv("RR_ROCTX") && atoi(getenv("RR_ROCTX")) != 0) c->roctx = roctx_load();
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_error = "rr_create: hipStreamCreate (copy stream) failed"; rr_destroy(c); return nullptr;
+    }
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&L.ev_ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&L.ev_consumed, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&L.ev_consumed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L.ev_copied, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "rr_create: lane stream/event creation failed"; rr_destroy(c); return nullptr;
         }
     }
@@ -557,6 +619,8 @@ void rr_destroy(rr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();   // frames may still be in flight on the lanes' or the caller's streams
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
     c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_beam_order2.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
@@ -567,9 +631,10 @@ void rr_destroy(rr_ctx* c)
         L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
+        if (L.ev_copied) (void)hipEventDestroy(L.ev_copied);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -588,6 +653,10 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     {
         const size_t nn = bvh.nodes.size(), nt = bvh.tris.size();
         int rc = check_bvh_size(c, nn, nt); if (rc) return rc;
+        // from here on the old tree is being overwritten: no mesh until the new one is complete (an error
+        // return below leaves the context without a mesh, never with a half-written one)
+        c->have_mesh = false;
+        for (Lane& L : c->lanes) L.buf_seg = 0;
         c->tri_base4 = (uint32_t)(nn * 8);
         RR_HIP(c, c->d_bvh.ensure(nn * 8 + (nt + 4) * 3));   // +4 triangles: a quad may fetch past a short leaf
         RR_HIP(c, hipMemcpy(c->d_bvh.p, bvh.nodes.data(), nn * sizeof(Node4), hipMemcpyHostToDevice));
@@ -620,6 +689,8 @@ int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* fa
         int rc = check_bvh_size(c, nn, nf);
         hipError_t e = hipSuccess;
         if (!rc) {
+            c->have_mesh = false;           // see rr_set_mesh: no mesh while the tree is being replaced
+            for (Lane& L : c->lanes) L.buf_seg = 0;
             c->tri_base4 = (uint32_t)(nn * 8);
             e = c->d_bvh.ensure(nn * 8 + (nf + 4) * 3);
             if (e == hipSuccess) e = hipMemcpy(c->d_bvh.p, dn, nn * sizeof(Node4), hipMemcpyDeviceToDevice);
@@ -708,6 +779,7 @@ int rr_set_noise_offsets(rr_ctx* c, const float* rnd, size_t n)
 {
     if (!c) return -1;
     if (n && !rnd) return fail(c, -3, "rr_set_noise_offsets: null pointer");
+    for (size_t i = 0; i < n; i++) if (!std::isfinite(rnd[i])) return fail(c, -3, "rr_set_noise_offsets: non-finite offset");
     c->noise.assign(rnd, rnd + n);
     c->tables_dirty |= rr_ctx::D_NOISE;
     return 0;
@@ -779,6 +851,60 @@ int rr_simulate_batch_device(rr_ctx* c, const float* poses, int n_frames, uint8_
     RR_HIP(c, hipGetLastError());
     RR_HIP(c, hipEventRecord(L.ev_consumed, s));
     L.pending_consume = true;
+    return 0;
+}
+
+void* rr_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void rr_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, uint8_t* h_imgs_u8, void* stream)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!poses || !h_imgs_u8) return fail(c, -3, "rr_simulate_batch_host_async: null poses/output");
+    if (n_frames < 1 || n_frames > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_batch_host_async: n_frames must be 1..64");
+    RR_HIP(c, hipSetDevice(c->device));
+    const rr_config& g = c->cfg;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = upload_tables(c); if (rc) return rc;
+    const size_t li = c->next_lane++ % c->lanes.size();
+    Lane& L = c->lanes[li];
+    c->last_lane = li;
+    const size_t bytes = (size_t)n_frames * g.n_cells * g.n_angles;
+    if (L.d_img_u8.n < bytes) {
+        RR_HIP(c, hipDeviceSynchronize());      // an earlier copy may still read the old buffer
+        RR_HIP(c, L.d_img_u8.ensure(bytes));
+    }
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
+    if (L.pending_copy) RR_HIP(c, hipStreamWaitEvent(s, L.ev_copied, 0));    // the lane's images are being copied out
+    rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames); if (rc) return rc;
+    { TimedScope t(c, s, "assemble");
+      launch_assemble_u8(L.d_cols_u8.p, L.d_img_u8.p, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
+                         (size_t)g.n_angles * g.n_cells, n_frames, (size_t)g.n_angles * g.n_cells); }
+    RR_HIP(c, hipGetLastError());
+    RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+    L.pending_consume = true;
+    // the D2H of this batch overlaps the kernels of the next one: own stream, ordered behind the assemble
+    RR_HIP(c, hipStreamWaitEvent(c->copy_stream, L.ev_consumed, 0));
+    if (c->roctx) roctx_push("image D2H");
+    RR_HIP(c, hipMemcpyAsync(h_imgs_u8, L.d_img_u8.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    if (c->roctx) roctx_pop();
+    RR_HIP(c, hipEventRecord(L.ev_copied, c->copy_stream));
+    L.pending_copy = true; L.copy_dst = h_imgs_u8;
+    return 0;
+}
+
+int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
+{
+    if (!c) return -1;
+    RR_HIP(c, hipSetDevice(c->device));
+    for (Lane& L : c->lanes)
+        if (L.pending_copy && (h_imgs_u8 == nullptr || L.copy_dst == h_imgs_u8)) RR_HIP(c, hipEventSynchronize(L.ev_copied));
     return 0;
 }
 
@@ -919,6 +1045,12 @@ int rr_synchronize(rr_ctx* c, void* stream)
     RR_HIP(c, hipSetDevice(c->device));
     for (Lane& L : c->lanes) RR_HIP(c, hipStreamSynchronize(L.stream));
     RR_HIP(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+    RR_HIP(c, hipStreamSynchronize(c->copy_stream));
+    // batches may run on OTHER caller streams as well (the header recommends four): a frame there could set a
+    // bit between the read and the clear below, so the whole device is drained first -- after this call no
+    // frame of this context is in flight anywhere and every error bit raised so far is reported exactly once
+    RR_HIP(c, hipDeviceSynchronize());
+    for (Lane& L : c->lanes) { L.pending_copy = false; L.copy_dst = nullptr; }
     // error bits of every frame the asynchronous entry points enqueued since the last call (a frame that
     // overflowed its wave queue or met a bad material id is truncated, never silently)
     uint32_t bits = 0;
@@ -1029,13 +1161,31 @@ int rr_get_kernel_time(rr_ctx* c, const char* kernel, double* total_ms, uint64_t
     KernelTimer& t = c->timers[kernel];
     for (auto& p : t.pending) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t.total_ms += ms; t.launches++; }
-        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t.total_ms += ms; t.launches++; t.samples_ms.push_back(ms); }
+        c->event_pool.push_back(p.first); c->event_pool.push_back(p.second);
     }
     t.pending.clear();
     if (total_ms) *total_ms = t.total_ms;
     if (launches) *launches = t.launches;
-    if (reset) { t.total_ms = 0.0; t.launches = 0; }
+    if (reset) { t.total_ms = 0.0; t.launches = 0; t.samples_ms.clear(); }
+    return 0;
+}
+
+int rr_get_kernel_samples(rr_ctx* c, const char* kernel, float* out_ms, size_t capacity, size_t* n_out)
+{
+    if (!c || !kernel || !n_out) return -1;
+    int rc = rr_get_kernel_time(c, kernel, nullptr, nullptr, 0); if (rc) return rc;
+    const KernelTimer& t = c->timers[kernel];
+    *n_out = t.samples_ms.size();
+    if (out_ms) for (size_t i = 0; i < t.samples_ms.size() && i < capacity; i++) out_ms[i] = t.samples_ms[i];
+    return 0;
+}
+
+int rr_reserve_timing_events(rr_ctx* c, size_t n)
+{
+    if (!c) return -1;
+    RR_HIP(c, hipSetDevice(c->device));
+    while (c->event_pool.size() < n) { hipEvent_t e = nullptr; RR_HIP(c, hipEventCreate(&e)); c->event_pool.push_back(e); }
     return 0;
 }
 

@@ -96,9 +96,10 @@ class AzimuthShard:
         """Single-frame step (frames_per_step == 1)."""
         return self.step([pose], stream)
 
-    def step(self, poses, stream=None):
+    def step(self, poses, stream=None, done_event=None):
         """Enqueue one step (`frames_per_step` poses, the same list on every rank); returns the
-        HBM tensor [fpr][n_cells][n_angles] that will hold this rank's mono8 image(s)."""
+        HBM tensor [fpr][n_cells][n_angles] that will hold this rank's mono8 image(s).
+        `done_event` (a torch.cuda.Event) is recorded on the slot's stream behind the step."""
         assert len(poses) == self.frames_per_step
         s = self.slots[self.k % len(self.slots)]
         self.k += 1
@@ -123,6 +124,8 @@ class AzimuthShard:
                                                 s.images.data_ptr(), sp)
             if s.done is not None:
                 s.done.record(s.stream)
+            if done_event is not None and s.stream is not None:
+                done_event.record(s.stream)
         self.last = s
         return s.images
 

@@ -20,7 +20,11 @@ SYMBOLS = [
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
-    "rr_get_kernel_time",
+    "rr_get_kernel_time", "rr_get_kernel_samples", "rr_reserve_timing_events",
+    "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_partition",
+    "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_ctx",
+    "rr_multi_set_mesh", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
+    "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
 ]
 
 
@@ -118,10 +122,35 @@ def lib():
     L.rr_debug_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.rr_get_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rr_get_kernel_samples.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rr_reserve_timing_events.argtypes = [vp, C.c_size_t]
+    L.rr_simulate_batch_host_async.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.rr_wait_host.argtypes = [vp, vp]
+    L.rr_host_alloc.restype = vp
+    L.rr_host_alloc.argtypes = [C.c_size_t]
+    L.rr_host_free.argtypes = [vp]
+    L.rr_host_free.restype = None
+    L.rr_partition.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rr_partition.restype = None
+    L.rr_create_multi.restype = vp
+    L.rr_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.rr_destroy_multi.argtypes = [vp]
+    L.rr_destroy_multi.restype = None
+    L.rr_multi_last_error.restype = C.c_char_p
+    L.rr_multi_last_error.argtypes = [vp]
+    L.rr_multi_device_count.argtypes = [vp]
+    L.rr_multi_ctx.restype = vp
+    L.rr_multi_ctx.argtypes = [vp, C.c_int]
+    L.rr_multi_set_mesh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.rr_multi_set_materials.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int32]
+    L.rr_multi_set_config.argtypes = [vp, C.POINTER(RRConfig)]
+    L.rr_multi_set_beam_samples.argtypes = [vp, vp, C.c_size_t]
+    L.rr_multi_set_noise_offsets.argtypes = [vp, vp, C.c_size_t]
+    L.rr_multi_set_motion_poses.argtypes = [vp, vp, C.c_size_t]
+    L.rr_multi_simulate.argtypes = [vp, vp, vp]
+    L.rr_multi_simulate_batch.argtypes = [vp, vp, C.c_int, vp]
     for n in SYMBOLS:
-        f = getattr(L, n)
-        if f.restype is C.c_int and n not in ("rr_abi_version",):
-            pass
+        getattr(L, n)
     _LIB = L
     return L
 
@@ -214,8 +243,9 @@ class Context:
         self._ck(self._L.rr_set_beam_samples(self._h, d.ctypes.data, len(d)))
 
     def set_noise_offsets(self, rnd):
-        r = np.ascontiguousarray(rnd, np.float32)
-        self._ck(self._L.rr_set_noise_offsets(self._h, r.ctypes.data, len(r)))
+        """[n_angles] offsets, or [k][n_angles] (flat or 2-D): frame f of a batch uses row f % k."""
+        r = np.ascontiguousarray(rnd, np.float32).ravel()
+        self._ck(self._L.rr_set_noise_offsets(self._h, r.ctypes.data, r.size))
 
     def set_motion_poses(self, poses):
         """include_motion: [n_angles][7] per-azimuth poses; None/empty switches it off."""
@@ -248,6 +278,14 @@ class Context:
         """Whole frames of up to 64 (RR_MAX_BATCH) poses in one set of launches on `stream`: images [n][n_cells][n_angles] in HBM."""
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
         self._ck(self._L.rr_simulate_batch_device(self._h, p.ctypes.data, len(p), d_imgs_ptr, stream))
+
+    def simulate_batch_host_async(self, poses, h_imgs_ptr, stream=None):
+        """Whole frames delivered to (page-locked) host memory [n][n_cells][n_angles]; complete after wait_host()."""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ck(self._L.rr_simulate_batch_host_async(self._h, p.ctypes.data, len(p), h_imgs_ptr, stream))
+
+    def wait_host(self, h_imgs_ptr=None):
+        self._ck(self._L.rr_wait_host(self._h, h_imgs_ptr))
 
     def simulate_batch_columns_device(self, poses, az_begin, az_end, d_cols_u8_ptr, stream=None):
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
@@ -309,6 +347,18 @@ class Context:
         self._ck(self._L.rr_get_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
+    def kernel_samples(self, name):
+        """Every launch duration (ms) recorded for `name` since the last reset."""
+        n = C.c_size_t()
+        self._ck(self._L.rr_get_kernel_samples(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        if n.value:
+            self._ck(self._L.rr_get_kernel_samples(self._h, name.encode(), out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def reserve_timing_events(self, n):
+        self._ck(self._L.rr_reserve_timing_events(self._h, int(n)))
+
     def bvh_info(self):
         a, b, d, s = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
         self._ck(self._L.rr_get_bvh_info(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(s)))
@@ -321,3 +371,101 @@ class Context:
         f = np.zeros(len(o), np.uint32)
         self._ck(self._L.rr_debug_trace(self._h, o.ctypes.data, d.ctypes.data, len(o), t.ctypes.data, f.ctypes.data))
         return t, f
+
+
+class HostImages:
+    """Page-locked host memory for images (rr_host_alloc), viewed as a numpy array."""
+
+    def __init__(self, shape):
+        self._L = lib()
+        self.shape = tuple(int(x) for x in shape)
+        n = int(np.prod(self.shape))
+        self.ptr = self._L.rr_host_alloc(n)
+        if not self.ptr:
+            raise RRError("rr_host_alloc(%d) failed" % n)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(self.ptr)).reshape(self.shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._L.rr_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def partition(n_angles, world, rank):
+    """rr_partition: the azimuth block [begin, end) of `rank` (pure host arithmetic, no GPU needed)."""
+    b, e = C.c_int(), C.c_int()
+    lib().rr_partition(int(n_angles), int(world), int(rank), C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+class MultiContext:
+    """rr_multi: several GPUs of one node behind one object (one process; RCCL inside the library)."""
+
+    def __init__(self, devices):
+        self._L = lib()
+        d = (C.c_int * len(devices))(*[int(x) for x in devices])
+        self._h = self._L.rr_create_multi(d, len(devices))
+        if not self._h:
+            raise RRError(self._L.rr_multi_last_error(None).decode())
+        self.cfg = None
+        self.n_angles = 400
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rr_destroy_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RRError("%s (rc=%d)" % (self._L.rr_multi_last_error(self._h).decode(), rc))
+
+    def device_count(self):
+        return self._L.rr_multi_device_count(self._h)
+
+    def set_mesh(self, verts, faces, face_object_id=None):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
+        o = None if face_object_id is None else np.ascontiguousarray(face_object_id, np.uint32)
+        self._ck(self._L.rr_multi_set_mesh(self._h, v.ctypes.data, len(v), f.ctypes.data, len(f), None if o is None else o.ctypes.data))
+
+    def set_materials(self, materials, object_materials, material_id_air=0):
+        m = (RRMaterial * len(materials))(*[RRMaterial(*[float(x) for x in (t.astuple() if hasattr(t, "astuple") else t)])
+                                            for t in materials])
+        om = np.ascontiguousarray(object_materials, np.int32)
+        self._ck(self._L.rr_multi_set_materials(self._h, m, len(materials), om.ctypes.data, len(om), int(material_id_air)))
+
+    def set_config(self, cfg, n_angles=400, **kw):
+        self.cfg, self.n_angles = cfg, n_angles
+        self._rrcfg = make_config(cfg, n_angles, **kw)
+        self._ck(self._L.rr_multi_set_config(self._h, C.byref(self._rrcfg)))
+
+    def set_beam_samples(self, dirs):
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        self._ck(self._L.rr_multi_set_beam_samples(self._h, d.ctypes.data, len(d)))
+
+    def set_noise_offsets(self, rnd):
+        r = np.ascontiguousarray(rnd, np.float32).ravel()
+        self._ck(self._L.rr_multi_set_noise_offsets(self._h, r.ctypes.data, r.size))
+
+    def simulate_batch(self, poses):
+        """-> uint8 [n][n_cells][n_angles] in host memory."""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        out = np.zeros((len(p), self.cfg.n_cells, self.n_angles), np.uint8)
+        self._ck(self._L.rr_multi_simulate_batch(self._h, p.ctypes.data, len(p), out.ctypes.data))
+        return out
+
+    def simulate(self, pose):
+        return self.simulate_batch([pose])[0]

@@ -66,7 +66,7 @@ def test_default_config_matches_reference_cfg(native_lib):
     assert c.n_angles == 400 and abs(c.theta_inc + 2 * 3.141592653589793 / 400) < 1e-8
     assert abs(c.wave_energy_threshold - 0.001) < 1e-9 and c.range_max == 1000.0
     assert c.record_multi_reflection == 1 and c.record_multi_path == 0
-    assert native_lib.lib().rr_abi_version() == 2
+    assert native_lib.lib().rr_abi_version() == 3
 
 
 def test_missing_library_fails_loudly(native_lib, monkeypatch, tmp_path):
@@ -88,3 +88,27 @@ def test_product_never_touches_the_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert not bad.search(txt), f
     assert n >= 10
+
+
+def test_partition_matches_the_python_shard_arithmetic(native_lib):
+    """rr_partition (the block a device of rr_multi renders) == dist.partition (the block a rank of the
+    torch.distributed path renders): contiguous, exhaustive, sizes differ by at most one column.  Pure host code."""
+    from radarays_ros_amd.dist import partition
+    for n_angles in (1, 7, 50, 399, 400, 401, 1000):
+        for world in (1, 2, 3, 4, 7, 8, 16, 64):
+            blocks = [native_lib.partition(n_angles, world, r) for r in range(world)]
+            assert blocks == [partition(n_angles, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n_angles
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            sizes = [e - b for b, e in blocks]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_multi_create_refuses_bad_device_lists(native_lib):
+    """No GPU here: rr_create_multi must fail with a message, never crash or fall back."""
+    L = native_lib.lib()
+    assert not L.rr_create_multi(None, 0)
+    assert b"1..64" in L.rr_multi_last_error(None)
+    d = (C.c_int * 2)(0, 0)
+    assert not L.rr_create_multi(d, 2)
+    assert b"twice" in L.rr_multi_last_error(None)

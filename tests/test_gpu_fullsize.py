@@ -72,17 +72,60 @@ def test_target_config_full_frame_vs_oracle(big, native_lib, oracle):
     assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1 and d["u8_mismatch_frac"] <= 1e-3, d
 
 
-def test_config4_1000_rays(big, native_lib):
+def test_bench_step_of_the_target_against_oracle(big, native_lib, oracle):
+    """What `python bench.py` times by default, checked directly: the 16-pose trajectory of the north-star target
+    (10M triangles, 400 x 200 rays, 4 passes, Perlin noise with one row of offsets per frame), rendered by the
+    batch entry point the bench step uses (8 poses per call), delivered to host memory like the reference's
+    m_polar_image; every mono8 image against the oracle's frame for that pose and that noise row."""
     s, c = big
-    cfg = params.kaist_preset(n_reflections=4, ambient_noise=2)
+    cfg = params.kaist_preset(n_reflections=4, n_samples=200, ambient_noise=2)
+    mats = materials_for(s)
+    noise = (np.random.RandomState(7).uniform(0, 1, (16, 400)) * 1000.0).astype(np.float32)
+    poses = scenes.trajectory(16, s["name"])
+    c.set_config(cfg)
+    c.set_beam_samples(golden_beams(200))
+    c.set_noise_offsets(noise)
+    host = native_lib.HostImages((16, cfg.n_cells, 400))
+    for k in range(2):       # a bench step = 8 poses; frame f of a batch uses noise row f % 16
+        c.set_noise_offsets(np.roll(noise, -8 * k, axis=0))
+        c.simulate_batch_host_async(poses[8 * k:8 * k + 8], host.ptr + 8 * k * cfg.n_cells * 400, None)
+        c.wait_host(None)
+    c.synchronize()
+    assert c.stats()["overflow"] == 0
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=1)
+    for f, p in enumerate(poses):
+        o8, _, _ = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, golden_beams(200), p,
+                                   noise_rnd=noise[f], want_f32=False)
+        d8 = np.abs(host.array[f].astype(np.int32) - o8.astype(np.int32))
+        assert d8.max() <= 1 and (d8 > 0).mean() <= 1e-3, (f, int(d8.max()), float((d8 > 0).mean()))
+    host.close()
+
+
+def test_config4_1000_rays(big, native_lib, oracle):
+    """configs[3] on one GPU: 400 x 1000 rays, 4 passes, 10M triangles: properties of the whole frame, the frame
+    sharded as 8 ranks would, and two azimuth pairs against the oracle (counts exact, mean deviation <= 1e-5)."""
+    s, c = big
+    cfg = params.kaist_preset(n_reflections=4, n_samples=1000, ambient_noise=2)
     c.set_config(cfg)
     c.set_beam_samples(golden_beams(1000))
-    c.set_noise_offsets((np.random.RandomState(7).uniform(0, 1, 400) * 1000).astype(np.float32))
-    img, _, st = c.simulate(scenes.default_pose(s["name"]))
+    rnd = (np.random.RandomState(7).uniform(0, 1, 400) * 1000).astype(np.float32)
+    c.set_noise_offsets(rnd)
+    pose = scenes.default_pose(s["name"])
+    img, _, st = c.simulate(pose)
     assert st["overflow"] == 0 and st["wave_passes"] >= 400000 and st["hits"] > 0.99 * st["wave_passes"]
     assert img.max() <= 255 and (img > 0).mean() > 0.5      # noise floor fills the image
-    again, _, _ = c.simulate(scenes.default_pose(s["name"]))
+    again, _, _ = c.simulate(pose)
     assert np.array_equal(img, again)
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=1)
+    mats = materials_for(s)
+    for az in ((11, 13), (301, 303)):
+        g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
+        assert np.array_equal(g8[:, az[0]:az[1]], img[:, az[0]:az[1]])       # a shard == the same columns of the frame
+        o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, golden_beams(1000), pose,
+                                      noise_rnd=rnd, az_begin=az[0], az_end=az[1])
+        assert gst["wave_passes"] == ost["wave_passes"] and gst["hits"] == ost["hits"] and gst["signals"] == ost["signals"], (gst, ost)
+        d = image_diff(gf[:, az[0]:az[1]], of[:, az[0]:az[1]], g8[:, az[0]:az[1]], o8[:, az[0]:az[1]])
+        assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1, d
 
 
 def test_config5_per_triangle_materials_8_passes(big, native_lib, oracle):

@@ -1,0 +1,162 @@
+"""GPU tests of the round-3 additions to the C ABI (include/radarays_mi355.h, ABI 3) and of the parity edges the
+round-2 review listed:
+  * rr_multi (several GPUs behind one object) with ONE device == rr_simulate, byte for byte
+  * rr_simulate_batch_host_async / rr_wait_host (images delivered to host memory, RadarCPU.cpp:542,555-561)
+  * material-set batches under several noise rows (advisor finding), noise-offset validation
+  * waves at the pruning threshold (RadarCPU.cpp:288,367): the one known divergence class, gated instead of excluded
+"""
+import numpy as np
+import pytest
+
+from common import golden_beams, image_diff, materials_for, mats_tuple
+from radarays_ros_amd import params, scenes
+from radarays_ros_amd.fixtures import random_room_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(obj, s, cfg, mats, beams, noise=None):
+    obj.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    obj.set_materials(mats, s["object_materials"], 0)
+    obj.set_config(cfg, 400)
+    obj.set_beam_samples(beams)
+    if noise is not None:
+        obj.set_noise_offsets(noise)
+
+
+@pytest.fixture(scope="module")
+def small():
+    s = scenes.heightfield_room(64, n_buildings=40, seed=3)      # 8k terrain triangles + 40 penetrable boxes
+    cfg = params.kaist_preset(n_reflections=3, n_samples=60, ambient_noise=2)
+    noise = (np.random.RandomState(5).uniform(0, 1, (4, 400)) * 1000.0).astype(np.float32)
+    return s, cfg, materials_for(s), golden_beams(60), noise, scenes.trajectory(6, s["name"])
+
+
+def test_multi_with_one_device_equals_rr_simulate(native_lib, small):
+    """rr_create_multi({0}): no collective runs, the same kernels, the same bytes as rr_simulate; a batch through
+    rr_multi_simulate_batch equals the frames one by one (noise row f % k for frame f of a batch)."""
+    s, cfg, mats, beams, noise, poses = small
+    m = native_lib.MultiContext([0])
+    assert m.device_count() == 1
+    _setup(m, s, cfg, mats, beams, noise)
+    c = native_lib.Context(0)
+    _setup(c, s, cfg, mats, beams, noise[0])
+    one, _, st = c.simulate(poses[0])
+    assert st["overflow"] == 0
+    assert np.array_equal(m.simulate(poses[0]), one)
+    got = m.simulate_batch(poses)
+    assert got.shape == (6, cfg.n_cells, 400)
+    for f, p in enumerate(poses):
+        c.set_noise_offsets(noise[f % 4])
+        ref, _, _ = c.simulate(p)
+        assert np.array_equal(got[f], ref), f
+    # errors come back as codes + text, per device
+    with pytest.raises(native_lib.RRError, match="n_frames must be 1..64"):
+        m.simulate_batch(np.zeros((65, 7), np.float32))
+    bad = np.array(poses[0]); bad[2] = np.nan
+    with pytest.raises(native_lib.RRError, match="device 0: non-finite pose"):
+        m.simulate(bad)
+    m.close(); c.close()
+    with pytest.raises(native_lib.RRError, match="device index out of range"):
+        native_lib.MultiContext([0, 977])
+
+
+def test_batch_host_async_delivers_the_same_images(native_lib, small):
+    """Images copied to page-locked host memory on the copy stream, several batches in flight on two streams:
+    every image equals rr_simulate's; rr_wait_host(ptr) waits for exactly that buffer."""
+    import torch
+    s, cfg, mats, beams, noise, poses = small
+    c = native_lib.Context(0)
+    _setup(c, s, cfg, mats, beams, noise[0])
+    ref = [c.simulate(p)[0] for p in poses]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [native_lib.HostImages((3, cfg.n_cells, 400)) for _ in range(6)]
+    for b in bufs:
+        b.array[:] = 7
+    order = []
+    for k in range(6):                       # 6 batches of 3 poses, more batches than lanes (4): lanes are reused
+        ps = [poses[(k + j) % 6] for j in range(3)]
+        c.simulate_batch_host_async(ps, bufs[k].ptr, streams[k % 2].cuda_stream)
+        order.append(ps)
+    c.wait_host(bufs[0].ptr)
+    for j in range(3):
+        assert np.array_equal(bufs[0].array[j], ref[j % 6])
+    c.wait_host(None)
+    c.synchronize()
+    for k in range(6):
+        for j in range(3):
+            assert np.array_equal(bufs[k].array[j], ref[(k + j) % 6]), (k, j)
+    # pageable memory works too (the copy then simply does not overlap)
+    out = np.zeros((2, cfg.n_cells, 400), np.uint8)
+    c.simulate_batch_host_async(poses[:2], out.ctypes.data, None)
+    c.synchronize()
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+    for b in bufs:
+        b.close()
+    c.close()
+
+
+def test_material_sets_with_several_noise_rows_use_row_0(native_lib, small):
+    """Advisor finding (round 2): with k >= 2 noise rows installed, set i of a parameter batch was rendered under
+    row i % k.  The header promises image k == rr_set_materials(sets[k]) + rr_simulate_device(pose): row 0 for all."""
+    s, cfg, mats, beams, noise, poses = small
+    c = native_lib.Context(0)
+    _setup(c, s, cfg, mats, beams, noise)            # 4 rows
+    base = np.asarray([m.astuple() for m in mats], np.float32)
+    sets = np.repeat(base[None], 5, axis=0)
+    sets[1:, 1:, 1] = np.random.RandomState(2).uniform(0.2, 1.0, (4, base.shape[0] - 1))
+    got = c.simulate_material_sets(poses[1], sets)
+    c.set_noise_offsets(noise[0])
+    for k in range(5):
+        c.set_materials([params.RadarMaterial(*[float(x) for x in sets[k, i]]) for i in range(sets.shape[1])],
+                        s["object_materials"], 0)
+        one, _, _ = c.simulate(poses[1])
+        assert np.array_equal(one, got[k]), k
+    c.close()
+
+
+def test_noise_offsets_are_validated(native_lib, small):
+    s, cfg, mats, beams, noise, poses = small
+    c = native_lib.Context(0)
+    _setup(c, s, cfg, mats, beams)
+    c.set_noise_offsets(noise)                       # 2-D [4][400]: accepted as 4 rows
+    c.simulate(poses[0])
+    bad = noise[0].copy(); bad[17] = np.inf
+    with pytest.raises(native_lib.RRError, match="non-finite offset"):
+        c.set_noise_offsets(bad)
+    c.set_noise_offsets(np.zeros(600, np.float32))   # neither one row nor whole rows: refused when the frame is set up
+    with pytest.raises(native_lib.RRError, match="multiple of n_angles"):
+        c.simulate(poses[0])
+    c.set_noise_offsets(noise[1])
+    c.simulate(poses[0])
+    c.close()
+
+
+def _threshold_seeds():
+    return [377] + list(range(2000, 2012))
+
+
+@pytest.mark.parametrize("seed", _threshold_seeds())
+def test_waves_at_the_pruning_threshold(native_lib, oracle, seed):
+    """A wave whose reflected / refracted energy lies within ~1e-7 of wave_energy_threshold (RadarCPU.cpp:288,367) is
+    kept by one libm's acosf and dropped by the other's: the reference does not define the last ulp either.  Seed 377
+    is such a scene (round 2 left it out of the default list).  Gate: when the oracle saw NO energy within 1e-6 of
+    the threshold the counts must be exact as everywhere else; when it saw n such waves the counts may differ by at
+    most the descendants of n waves (2^(remaining passes) each), and the image gate holds either way -- a wave of
+    energy 0.001 weighs 0.1 % of a full echo."""
+    s, cfg, mats, beams, pose, rnd, az = random_room_case(seed)
+    c = native_lib.Context(0)
+    _setup(c, s, cfg, mats, beams, rnd)
+    g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
+    c.close()
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
+    o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, beams, pose, noise_rnd=rnd,
+                                  az_begin=az[0], az_end=az[1])
+    near = ost["near_threshold"]
+    slack = near * (2 ** cfg.n_reflections)
+    if seed == 377:
+        assert near >= 1                      # the scene that motivated the gate really is of this class
+    for k in ("wave_passes", "hits", "signals"):
+        assert abs(gst[k] - ost[k]) <= slack, (k, gst, ost, near)
+    d = image_diff(gf, of, g8, o8)
+    assert d["mean_dev"] <= (1e-5 if near == 0 else 1e-4) and d["u8_max"] <= 1, (d, near)

@@ -34,7 +34,7 @@ static std::vector<T> slurp(const std::string& path)
 }
 
 struct RayRec { int32_t az, pass; float o[3], d[3]; };
-struct Cost { unsigned nodes = 0, leaves = 0, tris = 0; float t = -1.f; uint32_t face = 0xFFFFFFFFu; };
+struct Cost { unsigned nodes = 0, leaves = 0, tris = 0; float t = -1.f; uint32_t face = 0xFFFFFFFFu; unsigned nh[5] = {0,0,0,0,0}; unsigned leaves_after_hit = 0, nodes_after_hit = 0; };
 
 static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range_max)
 {
@@ -45,7 +45,7 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
         if (std::fabs(dk) < 1e-20f) dk = std::copysign(1e-20f, dk);
         inv[k] = 1.0f / dk; oo[k] = -o[k] * inv[k];
     }
-    uint32_t stack[256]; int sp = 0;
+    uint32_t stack[256]; float stack_t[256]; int sp = 0; static const bool cull_pop = getenv("TREEQ_CULL_POP") != nullptr;
     uint32_t cur = 0;
     float best_t = INFINITY; uint32_t best_face = 0xFFFFFFFFu;
     float tcull = range_max * 1.0001f + 1e-3f;
@@ -67,15 +67,18 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
                     key[nh] = (bits & ~3u) | (uint32_t)q; ref[nh] = ch.ref; nh++;
                 }
             }
+            c.nh[nh]++;
+            if (best_face != 0xFFFFFFFFu) c.nodes_after_hit++;
             if (nh > 0) {
                 // sort ascending by key
                 for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); }
-                for (int i = nh - 1; i >= 1; i--) stack[sp++] = ref[i];
+                for (int i = nh - 1; i >= 1; i--) { uint32_t kb = key[i] & ~3u; float tk; memcpy(&tk, &kb, 4); stack_t[sp] = tk; stack[sp++] = ref[i]; }
                 cur = ref[0];
                 continue;
             }
         } else {
             c.leaves++;
+            if (best_face != 0xFFFFFFFFu) c.leaves_after_hit++;
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
             for (uint32_t i = 0; i < cnt; i++) {
                 c.tris++;
@@ -95,6 +98,7 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
                 }
             }
         }
+        if (cull_pop) while (sp > 0 && stack_t[sp - 1] > tcull) sp--;
         if (sp == 0) break;
         cur = stack[--sp];
     }
@@ -163,6 +167,14 @@ int main(int argc, char** argv)
         printf("pass %d: %8zu rays  nodes/ray %6.2f  leaves/ray %5.2f  tris/ray %6.2f  steps/ray %6.2f  wave iterations (est.) %6.2f  bytes/ray %7.1f\n",
                kv.first, idx.size(), n / m, l / m, t / m, (n + l) / m, wave_steps / waves, (n * 128 + t * 48) / m + 132);
         tn += n; tl += l; tt += t; tr += idx.size(); tw += wave_steps; twv += waves;
+    }
+    {
+        double nh[5] = {0,0,0,0,0}, lah = 0, nah = 0; std::vector<unsigned> st;
+        for (const Cost& c : cost) { for (int k = 0; k < 5; k++) nh[k] += c.nh[k]; lah += c.leaves_after_hit; nah += c.nodes_after_hit; st.push_back(c.nodes + c.leaves); }
+        std::sort(st.begin(), st.end());
+        printf("node visits by number of hit children 0..4 per ray: %.2f %.2f %.2f %.2f %.2f; after the first hit was found: %.2f nodes, %.2f leaves per ray\n",
+               nh[0] / tr, nh[1] / tr, nh[2] / tr, nh[3] / tr, nh[4] / tr, nah / tr, lah / tr);
+        printf("steps per ray percentiles: p10 %u p50 %u p90 %u p99 %u max %u\n", st[st.size() / 10], st[st.size() / 2], st[st.size() * 9 / 10], st[st.size() * 99 / 100], st.back());
     }
     printf("all   : %8zu rays  nodes/ray %6.2f  leaves/ray %5.2f  tris/ray %6.2f  steps/ray %6.2f  wave iterations (est.) %6.2f  bytes/ray %7.1f\n",
            tr, tn / tr, tl / tr, tt / tr, (tn + tl) / tr, tw / twv, (tn * 128 + tt * 48) / tr + 132);
