@@ -215,8 +215,12 @@ def main():
     t1 = time.perf_counter()
     live = {n: ctx.kernel_time(n, reset=True) for n in ("trace", "trace0")}
     ctx.set_timing_mode(0)
-    # per-step periods: completion of step k-1 -> completion of step k (steps overlap, so this is the cadence)
-    periods_ms = [done[k].elapsed_time(done[k + 1]) for k in range(1, args.steps)]
+    # per-step times: steps overlap and may finish out of order (4 streams), so a single step has no duration of
+    # its own; what is defined is the cadence -- completion times in completion order, differenced over windows of
+    # `slots` completions (one window = as many steps as can be in flight)
+    tdone = sorted(done[0].elapsed_time(done[k]) for k in range(1, args.steps + 1))
+    win = max(1, min(args.slots, len(tdone) - 1))
+    periods_ms = [(tdone[i + win] - tdone[i]) / win for i in range(len(tdone) - win)]
 
     elapsed = t1 - t0
     if world > 1:
@@ -235,16 +239,19 @@ def main():
         npx = cfg.n_cells * params.N_ANGLES
         F = args.frames_per_rank
         streams = [torch.cuda.Stream(device=dev) for _ in range(args.slots)]
-        hosts = [native.HostImages((F, cfg.n_cells, params.N_ANGLES)) for _ in range(args.slots)]
+        # a ring of host buffers twice as deep as the batches in flight: the consumer side (rr_wait_host before a
+        # buffer is handed out again) then never stalls the producer
+        hosts = [native.HostImages((F, cfg.n_cells, params.N_ANGLES)) for _ in range(2 * args.slots)]
         state = {"n": 0}
 
         def step_host(k):
             for b in range(bps):
-                i = state["n"] % args.slots
+                n = state["n"]
                 state["n"] += 1
-                ctx.wait_host(hosts[i].ptr)           # the consumer is done with this buffer (nothing to do here)
+                h = hosts[n % len(hosts)]
+                ctx.wait_host(h.ptr)                  # the images this buffer received 2 x slots batches ago are complete
                 ctx.simulate_batch_host_async([poses[((k * bps + b) * F + f) % len(poses)] for f in range(F)],
-                                              hosts[i].ptr, streams[i].cuda_stream)
+                                              h.ptr, streams[n % args.slots].cuda_stream)
         prewarm(step_host)
         ctx.wait_host(None); torch.cuda.synchronize()
         th0 = time.perf_counter()
@@ -347,7 +354,7 @@ def main():
             "images_per_s_per_step": {"median": round(fps / (1e-3 * pct(periods_ms, 0.5)), 2) if periods_ms else None,
                                       "p10": round(fps / (1e-3 * pct(periods_ms, 0.9)), 2) if periods_ms else None,
                                       "p90": round(fps / (1e-3 * pct(periods_ms, 0.1)), 2) if periods_ms else None,
-                                      "basis": "completion-to-completion period of consecutive steps (hip events)"},
+                                      "basis": "cadence of step completions (hip events), differenced over windows of %d completions" % win},
             "prewarm_s": PREWARM_S,
             "host_resident": host_res,
             "single_pose": single,

@@ -15,6 +15,8 @@
 #include "rr_device.h"
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+
 namespace rr {
 
 // ---------------------------------------------------------------------------
@@ -813,6 +815,10 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         // ballot rank inside the wave + the counts of the waves before it (the per-wave slots of the last
         // pass are half empty -- no multipath echo -- so the replay scans half as many entries)
         int n = 0;
+        // 64-bin tiles touched by the kept signals of this chunk: collected per lane in registers and OR-ed into LDS
+        // once per wave (one LDS atomic per signal and tile put every lane of a wave on the same two addresses:
+        // 10.4 M bank-conflict cycles per launch on the 10M-triangle target, profiles/r02c_t_pmc_summary.json)
+        unsigned long long tm0 = 0ull, tm1 = 0ull;
         for (int r0 = 0; r0 < n_in; r0 += kColThreads) {
             const int i = r0 + tid;
             const int v = c0 + i;
@@ -836,11 +842,14 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 s_sig[pos] = r;
                 int lo = r.cell - mode, hi = r.cell - mode + W - 1;
                 lo = max(lo, 0); hi = min(hi, n_cells - 1);
-                for (int t = lo >> 6; t <= (hi >> 6); t++) atomicOr(&s_tiles[t >> 6], 1ull << (t & 63));
+                for (int t = lo >> 6; t <= (hi >> 6); t++) { if (t < 64) tm0 |= 1ull << t; else tm1 |= 1ull << (t - 64); }
             }
             n += total;
             __syncthreads();
         }
+        for (int off = 32; off > 0; off >>= 1) { tm0 |= __shfl_xor(tm0, off); tm1 |= __shfl_xor(tm1, off); }
+        if (lane == 0) { if (tm0) atomicOr(&s_tiles[0], tm0); if (tm1) atomicOr(&s_tiles[1], tm1); }
+        __syncthreads();
         for (int t = wid; t < n_tiles; t += kColWaves) {
             if (!((s_tiles[t >> 6] >> (t & 63)) & 1ull)) continue;
             const int g = t * 64 + lane;
@@ -1095,8 +1104,12 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     // pass 0: one flat sequence of n_seg x n_beam rays; later passes: a row of blocks per segment
     const int A0 = P.pass0_az, Sw0 = kRaysPerWave / A0;
     const size_t waves0 = (size_t)((n_seg + A0 - 1) / A0) * (size_t)((P.n_beam + Sw0 - 1) / Sw0);
+    // later passes: a segment holds at most n_beam * 2^pass waves (each wave has <= 2 children) -- no blocks are
+    // launched beyond that bound (pass 1 of the KAIST preset: 13 instead of 50 blocks per segment; the rest would
+    // read their segment's count and exit)
+    const long bound = std::min<long>((long)P.cap, pass < 20 ? (long)P.n_beam << pass : (long)P.cap);
     dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + 1) / 2))
-                          : dim3((P.cap + kRaysPerBlock - 1) / kRaysPerBlock, n_seg);
+                          : dim3((unsigned)((bound + kRaysPerBlock - 1) / kRaysPerBlock), n_seg);
     dim3 block(kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
     const bool spill = P.spill_depth > 0;
@@ -1115,7 +1128,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
 
 void launch_shade(const Params& P, int pass, hipStream_t s)
 {
-    const int cap_p = pass == 0 ? P.n_beam : P.cap;
+    const int cap_p = (int)std::min<long>((long)P.cap, pass < 20 ? (long)P.n_beam << pass : (long)P.cap);   // see launch_trace
     dim3 grid((cap_p + 63) / 64, P.n_seg), block(64);
     if (pass == 0) hipLaunchKernelGGL((k_shade<true>), grid, block, 0, s, P, pass);
     else           hipLaunchKernelGGL((k_shade<false>), grid, block, 0, s, P, pass);
