@@ -178,8 +178,9 @@ int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint
 
 /* The reference leaves every frame in HOST memory (m_polar_image -> sensor_msgs::Image, RadarCPU.cpp:542,555-561).
  * Whole frames of n_frames poses like rr_simulate_batch_device, delivered to the caller's host buffer
- * h_imgs_u8 = [n_frames][n_cells][n_angles]: kernels on `stream`, then ONE D2H copy on the context's copy stream,
- * so the copy of a batch overlaps the kernels of the next one.  Returns at once; the images are complete after
+ * h_imgs_u8 = [n_frames][n_cells][n_angles]: kernels, then ONE D2H copy, all ordered on `stream`; batches in flight
+ * on the caller's other streams keep the GPU busy meanwhile (four streams in total is the measured optimum: HIP
+ * maps streams onto four hardware queues).  Returns at once; the images are complete after
  * rr_wait_host(ctx, h_imgs_u8) (NULL: every outstanding copy) or rr_synchronize().  For a copy that really
  * overlaps, h_imgs_u8 must be page-locked: rr_host_alloc / rr_host_free (hipHostMalloc). */
 int rr_simulate_batch_host_async(rr_ctx* ctx, const float* poses, int n_frames, uint8_t* h_imgs_u8, void* stream);
@@ -224,7 +225,7 @@ int rr_assemble_frames_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, 
  * column buffer + rr_assemble_image_device into d_img_u8.  Asynchronous. */
 int rr_simulate_device(rr_ctx* ctx, const float pose_qxyzw_t[7], uint8_t* d_img_u8, void* stream);
 
-/* Blocks until `stream` (NULL = ctx stream), the ctx's own frame lanes and copy stream -- and, because batches may
+/* Blocks until `stream` (NULL = ctx stream) and the ctx's own frame lanes -- and, because batches may
  * have been issued on further caller streams, everything else on the device -- are idle, then reports what
  * the asynchronous (*_device) entry points could not: -7 if any frame enqueued since the last call
  * exceeded its wave/signal queue capacity, -8 if one met an object/material id outside the tables

@@ -146,8 +146,6 @@ struct rr_ctx {
         hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
     }
 
-    // host-image delivery (rr_simulate_batch_host_async): one copy stream for all D2H traffic
-    hipStream_t copy_stream = nullptr;
     bool roctx = false;
 };
 
@@ -598,9 +596,6 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_PASS0_AZ")) { const int a = atoi(getenv("RR_PASS0_AZ")); if (a == 1 || a == 2 || a == 4 || a == 8 || a == 16) c->pass0_az = a; }
     if (getenv("RR_STACK_LDS")) c->stack_lds_max = std::max(1, std::min(64, atoi(getenv("RR_STACK_LDS"))));
     if (getenv("RR_ROCTX") && atoi(getenv("RR_ROCTX")) != 0) c->roctx = roctx_load();
-    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
-        g_create_error = "rr_create: hipStreamCreate (copy stream) failed"; rr_destroy(c); return nullptr;
-    }
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -620,7 +615,6 @@ void rr_destroy(rr_ctx* c)
     (void)hipDeviceSynchronize();   // frames may still be in flight on the lanes' or the caller's streams
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
     c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_beam_order2.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
@@ -880,21 +874,27 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
         RR_HIP(c, hipDeviceSynchronize());      // an earlier copy may still read the old buffer
         RR_HIP(c, L.d_img_u8.ensure(bytes));
     }
-    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
-    if (L.pending_copy) RR_HIP(c, hipStreamWaitEvent(s, L.ev_copied, 0));    // the lane's images are being copied out
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));   // incl. the lane's last D2H copy
     rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames); if (rc) return rc;
     { TimedScope t(c, s, "assemble");
       launch_assemble_u8(L.d_cols_u8.p, L.d_img_u8.p, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
                          (size_t)g.n_angles * g.n_cells, n_frames, (size_t)g.n_angles * g.n_cells); }
     RR_HIP(c, hipGetLastError());
+    // The D2H is ordered on the SAME stream behind the assemble (a blit kernel: 0.2 ms per 8 images alone, 0.27-0.39 ms
+    // beside the other batches).  Measured on the 10M-triangle target (tools/probe_hostpath.py, 8 poses per batch,
+    // 4 streams; 3,950-3,975 images/s with the images left in HBM): this form 3,670-3,775; a separate copy stream
+    // beside 4 batch streams 3,250-3,590 (HIP maps streams onto 4 hardware queues: the fifth shares one with a batch
+    // stream and its event waits stall that batch), beside 3 batch streams 3,700-3,840; the assemble kernel writing
+    // straight into the host buffer 3,515; an own copy kernel of 4..128 workgroups 3,590-3,650; the copy folded into
+    // the next batch's pass-1 trace launch (8..400 extra grid rows, no dispatch of its own) 3,580-3,650.  Whatever
+    // issues the stores, the frame rate drops by about the PCIe transfer time of the images (11 MB at 54 GB/s =
+    // 0.2 ms per 2 ms batch): on this platform device -> host traffic does not overlap the kernels.
+    if (c->roctx) roctx_push("image D2H");
+    RR_HIP(c, hipMemcpyAsync(h_imgs_u8, L.d_img_u8.p, bytes, hipMemcpyDeviceToHost, s));
+    if (c->roctx) roctx_pop();
+    RR_HIP(c, hipEventRecord(L.ev_copied, s));
     RR_HIP(c, hipEventRecord(L.ev_consumed, s));
     L.pending_consume = true;
-    // the D2H of this batch overlaps the kernels of the next one: own stream, ordered behind the assemble
-    RR_HIP(c, hipStreamWaitEvent(c->copy_stream, L.ev_consumed, 0));
-    if (c->roctx) roctx_push("image D2H");
-    RR_HIP(c, hipMemcpyAsync(h_imgs_u8, L.d_img_u8.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
-    if (c->roctx) roctx_pop();
-    RR_HIP(c, hipEventRecord(L.ev_copied, c->copy_stream));
     L.pending_copy = true; L.copy_dst = h_imgs_u8;
     return 0;
 }
@@ -904,7 +904,10 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
     for (Lane& L : c->lanes)
-        if (L.pending_copy && (h_imgs_u8 == nullptr || L.copy_dst == h_imgs_u8)) RR_HIP(c, hipEventSynchronize(L.ev_copied));
+        if (L.pending_copy && (h_imgs_u8 == nullptr || L.copy_dst == h_imgs_u8)) {
+            RR_HIP(c, hipEventSynchronize(L.ev_copied));
+            L.pending_copy = false; L.copy_dst = nullptr;
+        }
     return 0;
 }
 
@@ -1045,7 +1048,6 @@ int rr_synchronize(rr_ctx* c, void* stream)
     RR_HIP(c, hipSetDevice(c->device));
     for (Lane& L : c->lanes) RR_HIP(c, hipStreamSynchronize(L.stream));
     RR_HIP(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
-    RR_HIP(c, hipStreamSynchronize(c->copy_stream));
     // batches may run on OTHER caller streams as well (the header recommends four): a frame there could set a
     // bit between the read and the clear below, so the whole device is drained first -- after this call no
     // frame of this context is in flight anywhere and every error bit raised so far is reported exactly once

@@ -62,7 +62,7 @@ def test_multi_with_one_device_equals_rr_simulate(native_lib, small):
 
 
 def test_batch_host_async_delivers_the_same_images(native_lib, small):
-    """Images copied to page-locked host memory on the copy stream, several batches in flight on two streams:
+    """Images copied to page-locked host memory (copy ordered behind each batch on its stream), several batches in flight on two streams:
     every image equals rr_simulate's; rr_wait_host(ptr) waits for exactly that buffer."""
     import torch
     s, cfg, mats, beams, noise, poses = small
