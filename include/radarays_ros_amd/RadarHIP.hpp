@@ -100,25 +100,35 @@ protected:
 
 class RadarHIP : public Radar {   // sibling of RadarCPU (RadarCPU.hpp:16-37)
 public:
+    // One backend object per process like the reference (radar_simulator.cpp:145-176); `devices` lists the GPUs
+    // of this node it fans out over (rr_multi: azimuth blocks, one RCCL collective per frame).
     RadarHIP(std::string map_frame, std::string sensor_frame, const std::vector<float>& verts,
-             const std::vector<uint32_t>& faces, const std::vector<uint32_t>& face_object, int device = 0)
+             const std::vector<uint32_t>& faces, const std::vector<uint32_t>& face_object, const std::vector<int>& devices)
     : Radar(std::move(map_frame), std::move(sensor_frame))
     {
-        m_ctx = rr_create(device);
-        if (!m_ctx) throw std::runtime_error(rr_last_error(nullptr));
-        if (rr_set_mesh(m_ctx, verts.data(), verts.size() / 3, faces.data(), faces.size() / 3,
-                        face_object.empty() ? nullptr : face_object.data())) {
-            std::string e = rr_last_error(m_ctx); rr_destroy(m_ctx); throw std::runtime_error(e);
+        m_multi = rr_create_multi(devices.data(), (int)devices.size());
+        if (!m_multi) throw std::runtime_error(rr_multi_last_error(nullptr));
+        m_ctx = rr_multi_ctx(m_multi, 0);
+        if (rr_multi_set_mesh(m_multi, verts.data(), verts.size() / 3, faces.data(), faces.size() / 3,
+                              face_object.empty() ? nullptr : face_object.data())) {
+            std::string e = rr_multi_last_error(m_multi); rr_destroy_multi(m_multi); throw std::runtime_error(e);
         }
     }
-    ~RadarHIP() override { rr_destroy(m_ctx); }
+    RadarHIP(std::string map_frame, std::string sensor_frame, const std::vector<float>& verts,
+             const std::vector<uint32_t>& faces, const std::vector<uint32_t>& face_object, int device = 0)
+    : RadarHIP(std::move(map_frame), std::move(sensor_frame), verts, faces, face_object, std::vector<int>{ device }) {}
+    ~RadarHIP() override { rr_destroy_multi(m_multi); }
     RadarHIP(const RadarHIP&) = delete;
     RadarHIP& operator=(const RadarHIP&) = delete;
 
     // m_waves_start: the reference draws them with sample_cone_local from std::random_device
     // (RadarCPU.cpp:136-145); here they are supplied (any generator) -- [n][3], local frame
     void setBeamSamples(const std::vector<float>& dirs) { m_waves_start = dirs; m_resample = false; m_push_beams = true; }
-    void setNoiseOffsets(const std::vector<float>& rnd) { rr_set_noise_offsets(m_ctx, rnd.data(), rnd.size()); }
+    void setNoiseOffsets(const std::vector<float>& rnd) { rr_multi_set_noise_offsets(m_multi, rnd.data(), rnd.size()); }
+    // include_motion (cfg/RadarModel.cfg:85, RadarCPU.cpp:190-196): the reference looks Tsm up once PER AZIMUTH while
+    // the antenna turns; the TF lookups of one sweep arrive here as [n_angles][7] and are used while
+    // m_cfg.include_motion is set (an empty vector: one pose per frame again)
+    void setMotionPoses(const std::vector<float>& poses_per_azimuth) { m_motion = poses_per_azimuth; m_push_motion = true; }
 
     ImagePtr simulate(double stamp) override   // RadarCPU.cpp:30-564
     {
@@ -131,7 +141,9 @@ public:
         msg = std::make_shared<Image>();
         msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;
         msg->data.assign((size_t)msg->height * msg->width, 0);
-        if (rr_simulate(m_ctx, Tsm_last, 0, m_n_angles, msg->data.data(), nullptr, &m_stats)) { msg.reset(); return fail(); }
+        if (rr_multi_device_count(m_multi) > 1) {
+            if (rr_multi_simulate(m_multi, Tsm_last, msg->data.data())) { msg.reset(); m_err = rr_multi_last_error(m_multi); std::cout << "[RadarHIP] " << m_err << std::endl; return {}; }
+        } else if (rr_simulate(m_ctx, Tsm_last, 0, m_n_angles, msg->data.data(), nullptr, &m_stats)) { msg.reset(); return fail(); }
         msg->stamp = stamp; msg->frame_id = m_sensor_frame;   // RadarCPU.cpp:560-561
         return msg;
     }
@@ -191,8 +203,14 @@ private:
             c.ambient_noise_energy_min = m_cfg.ambient_noise_energy_min;
             c.ambient_noise_energy_loss = m_cfg.ambient_noise_energy_loss;
             c.wave_energy_threshold = m_wave_energy_threshold;
-            if (rr_set_config(m_ctx, &c)) { fail(); return false; }
-            m_n_angles = c.n_angles; m_dirty_cfg = false;
+            c.range_max = 1000.0f;                  // make_model: range.max of the OnDn model (radar_algorithms.cpp:158)
+            if (rr_multi_set_config(m_multi, &c)) { mfail(); return false; }
+            m_n_angles = c.n_angles; m_dirty_cfg = false; m_push_motion = true;
+        }
+        if (m_push_motion) {
+            const bool on = m_cfg.include_motion && m_motion.size() == 7 * (size_t)m_n_angles;
+            if (rr_multi_set_motion_poses(m_multi, on ? m_motion.data() : nullptr, on ? (size_t)m_n_angles : 0)) { mfail(); return false; }
+            m_push_motion = false;
         }
         if (m_dirty_mat) {
             std::vector<rr_material> mats(m_params.materials.size());
@@ -201,17 +219,20 @@ private:
                 mats[i] = { m.velocity, m.ambient, m.diffuse, m.specular };
             }
             std::vector<int32_t> om(m_object_materials.begin(), m_object_materials.end());
-            if (rr_set_materials(m_ctx, mats.data(), mats.size(), om.data(), om.size(), m_material_id_air)) { fail(); return false; }
+            if (rr_multi_set_materials(m_multi, mats.data(), mats.size(), om.data(), om.size(), m_material_id_air)) { mfail(); return false; }
             m_dirty_mat = false;
         }
         if (m_push_beams) {
-            if (rr_set_beam_samples(m_ctx, m_waves_start.data(), m_waves_start.size() / 3)) { fail(); return false; }
+            if (rr_multi_set_beam_samples(m_multi, m_waves_start.data(), m_waves_start.size() / 3)) { mfail(); return false; }
             m_push_beams = false;
         }
         return true;
     }
     ImagePtr fail() { m_err = rr_last_error(m_ctx); std::cout << "[RadarHIP] " << m_err << std::endl; return {}; }
-    rr_ctx* m_ctx = nullptr;
+    void mfail() { m_err = rr_multi_last_error(m_multi); std::cout << "[RadarHIP] " << m_err << std::endl; }
+    rr_multi* m_multi = nullptr;     // owns one context per device (and the RCCL communicator when there are several)
+    rr_ctx* m_ctx = nullptr;         // = the context of the first device (statistics, parameter batches)
+    std::vector<float> m_motion; bool m_push_motion = false;
     int m_n_angles = 400;
     bool m_push_beams = false;
     rr_stats m_stats{};

@@ -54,6 +54,20 @@ int main(int argc, char** argv)
         if (batch.size() != 2 || batch[0]->data != img->data || batch[1]->data == img->data) {
             std::fprintf(stderr, "simulateMaterialSets mismatch: %s\n", radar.lastError().c_str()); return 7;
         }
+        // the same backend constructed over a device LIST (rr_multi; one device here): identical bytes
+        {
+            RadarHIP multi("map", "navtech", verts, faces, fobj, std::vector<int>{ 0 });
+            multi.loadParams(m, std::vector<int>(objmat.begin(), objmat.end()), 0);
+            multi.updateDynCfg(cfg); multi.setBeamSamples(beams); multi.updateTsm(pose.data());
+            ImagePtr img2 = multi.simulate(42.5);
+            if (!img2 || img2->data != img->data) { std::fprintf(stderr, "device-list backend differs: %s\n", multi.lastError().c_str()); return 8; }
+            // include_motion with the SAME pose for every azimuth is the same frame
+            std::vector<float> sweep; for (int a = 0; a < 400; a++) sweep.insert(sweep.end(), pose.begin(), pose.end());
+            RadarModelConfig cm = cfg; cm.include_motion = true;
+            multi.updateDynCfg(cm); multi.setMotionPoses(sweep);
+            ImagePtr img3 = multi.simulate(42.5);
+            if (!img3 || img3->data != img->data) { std::fprintf(stderr, "include_motion sweep differs: %s\n", multi.lastError().c_str()); return 9; }
+        }
         const rr_stats& st = radar.lastStats();
         std::printf("ok %u x %u wave_passes %llu signals %llu\n", img->height, img->width,
                     (unsigned long long)st.wave_passes, (unsigned long long)st.signals);
