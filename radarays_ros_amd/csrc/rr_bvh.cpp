@@ -17,6 +17,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <future>
 #include <limits>
@@ -108,6 +109,8 @@ struct Clipper {
     }
 };
 
+constexpr size_t kChunk = (size_t)1 << 16;   // references per work item of the intra-node loops (fixed: the tree does not depend on the thread count)
+
 struct Builder {
     Clipper clip;
     Node2* nodes; size_t node_cap;
@@ -115,7 +118,7 @@ struct Builder {
     std::atomic<uint32_t> next_node{1};
     std::atomic<uint64_t> next_leaf{0};
     std::atomic<int64_t> budget;          // extra references spatial splits may still create
-    std::atomic<int> tasks_left;
+    std::atomic<int> tasks_left;          // threads that may still be started (subtree tasks and chunk workers)
     std::atomic<bool> failed{false};
     std::atomic<uint64_t> n_spatial{0}, n_refs_out{0};
     float root_area = 0.f, alpha = 1e-5f;
@@ -123,6 +126,41 @@ struct Builder {
 
     struct ObjSplit { float cost; int axis, bin; Box lbox, rbox; };
     struct SpaSplit { float cost; int axis, bin; float pos; uint32_t nl, nr; };
+    struct Bounds { Box nb, cb; void reset() { nb.reset(); cb.reset(); } void grow(const Bounds& o) { nb.grow(o.nb); cb.grow(o.cb); } };
+
+    int acquire(int want) {
+        int got = 0;
+        while (got < want) {
+            int cur = tasks_left.load();
+            if (cur <= 0) break;
+            const int take = std::min(cur, want - got);
+            if (tasks_left.compare_exchange_weak(cur, cur - take)) got += take;
+        }
+        return got;
+    }
+    void release(int k) { if (k > 0) tasks_left.fetch_add(k); }
+
+    // f(chunk, begin, end) over fixed-size chunks of [0, n), on this thread plus as many workers as are free
+    template <class F> void for_chunks(size_t n, F&& f) {
+        const size_t nchunks = (n + kChunk - 1) / kChunk;
+        if (nchunks <= 1) { if (n) f((size_t)0, (size_t)0, n); return; }
+        const int extra = acquire((int)std::min<size_t>(nchunks - 1, 255));
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= nchunks) break;
+                f(c, c * kChunk, std::min(n, (c + 1) * kChunk));
+            }
+        };
+        std::vector<std::thread> th;
+        th.reserve((size_t)extra);
+        for (int i = 0; i < extra; i++) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        release(extra);
+    }
+    static size_t n_chunks(size_t n) { return std::max<size_t>(1, (n + kChunk - 1) / kChunk); }
 
     void make_leaf(uint32_t ni, const std::vector<Ref>& refs) {
         const uint64_t first = next_leaf.fetch_add(refs.size());
@@ -133,20 +171,41 @@ struct Builder {
     }
 
     static inline float centroid(const Ref& r, int ax) { return 0.5f * (r.box.lo[ax] + r.box.hi[ax]); }
+    static inline void grow_bounds(Bounds& b, const Ref& r) {
+        b.nb.grow(r.box);
+        const float c[3] = { centroid(r, 0), centroid(r, 1), centroid(r, 2) };
+        b.cb.grow_pt(c);
+    }
 
-    ObjSplit best_object_split(const std::vector<Ref>& refs, const Box& cb) const {
+    // binned SAH object split over the three axes: ONE pass over the references (chunk-parallel)
+    struct ObjBins { Box bb[3][kBins]; uint32_t bc[3][kBins]; };
+    ObjSplit best_object_split(const std::vector<Ref>& refs, const Box& cb) {
+        float lo[3], scale[3]; bool use[3];
+        for (int ax = 0; ax < 3; ax++) {
+            const float ext = cb.hi[ax] - cb.lo[ax];
+            use[ax] = ext > 0.f; lo[ax] = cb.lo[ax]; scale[ax] = use[ax] ? (float)kBins / ext : 0.f;
+        }
+        std::vector<ObjBins> part(n_chunks(refs.size()));
+        for_chunks(refs.size(), [&](size_t c, size_t b0, size_t b1) {
+            ObjBins& B = part[c];
+            for (int ax = 0; ax < 3; ax++) for (int b = 0; b < kBins; b++) { B.bb[ax][b].reset(); B.bc[ax][b] = 0; }
+            for (size_t i = b0; i < b1; i++) {
+                const Ref& r = refs[i];
+                for (int ax = 0; ax < 3; ax++) {
+                    if (!use[ax]) continue;
+                    int b = (int)((centroid(r, ax) - lo[ax]) * scale[ax]);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    B.bc[ax][b]++; B.bb[ax][b].grow(r.box);
+                }
+            }
+        });
+        ObjBins& T = part[0];
+        for (size_t c = 1; c < part.size(); c++)
+            for (int ax = 0; ax < 3; ax++) for (int b = 0; b < kBins; b++) { T.bc[ax][b] += part[c].bc[ax][b]; if (part[c].bc[ax][b]) T.bb[ax][b].grow(part[c].bb[ax][b]); }
         ObjSplit best; best.cost = std::numeric_limits<float>::infinity(); best.axis = -1; best.bin = 0;
         for (int ax = 0; ax < 3; ax++) {
-            const float lo = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
-            if (!(ext > 0.f)) continue;
-            Box bb[kBins]; uint32_t bc[kBins];
-            for (int b = 0; b < kBins; b++) { bb[b].reset(); bc[b] = 0; }
-            const float scale = (float)kBins / ext;
-            for (const Ref& r : refs) {
-                int b = (int)((centroid(r, ax) - lo) * scale);
-                b = std::min(std::max(b, 0), kBins - 1);
-                bc[b]++; bb[b].grow(r.box);
-            }
+            if (!use[ax]) continue;
+            const Box* bb = T.bb[ax]; const uint32_t* bc = T.bc[ax];
             Box lb[kBins]; uint32_t lc[kBins];
             Box acc; acc.reset(); uint32_t c = 0;
             for (int b = 0; b < kBins - 1; b++) { if (bc[b]) acc.grow(bb[b]); c += bc[b]; lb[b] = acc; lc[b] = c; }
@@ -162,65 +221,90 @@ struct Builder {
         return best;
     }
 
-    SpaSplit best_spatial_split(const std::vector<Ref>& refs, const Box& nb) const {
-        SpaSplit best; best.cost = std::numeric_limits<float>::infinity(); best.axis = -1; best.bin = 0; best.pos = 0.f; best.nl = best.nr = 0;
+    // binned spatial split (Stich et al. §4.2): references are chopped into the bins they span; one pass, chunk-parallel
+    struct SpaBins { Box bb[3][kBins]; uint32_t en[3][kBins], ex[3][kBins]; };
+    SpaSplit best_spatial_split(const std::vector<Ref>& refs, const Box& nb) {
+        float lo[3], scale[3], width[3]; bool use[3];
         for (int ax = 0; ax < 3; ax++) {
-            const float lo = nb.lo[ax], ext = nb.hi[ax] - nb.lo[ax];
-            if (!(ext > 0.f)) continue;
-            const float scale = (float)kBins / ext, width = ext / (float)kBins;
-            Box bb[kBins]; uint32_t entry[kBins], exit_[kBins];
-            for (int b = 0; b < kBins; b++) { bb[b].reset(); entry[b] = exit_[b] = 0; }
-            for (const Ref& r : refs) {
-                int b0 = (int)((r.box.lo[ax] - lo) * scale), b1 = (int)((r.box.hi[ax] - lo) * scale);
-                b0 = std::min(std::max(b0, 0), kBins - 1); b1 = std::min(std::max(b1, b0), kBins - 1);
-                entry[b0]++; exit_[b1]++;
-                if (b0 == b1) { bb[b0].grow(r.box); continue; }
-                for (int b = b0; b <= b1; b++) {
-                    const float plo = b == b0 ? -std::numeric_limits<float>::infinity() : lo + (float)b * width;
-                    const float phi = b == b1 ? std::numeric_limits<float>::infinity() : lo + (float)(b + 1) * width;
-                    Box cb = clip.slab(r.face, ax, plo, phi);
-                    cb.clip_to(r.box);
-                    if (cb.valid()) bb[b].grow(cb);
+            const float ext = nb.hi[ax] - nb.lo[ax];
+            use[ax] = ext > 0.f; lo[ax] = nb.lo[ax]; scale[ax] = use[ax] ? (float)kBins / ext : 0.f; width[ax] = ext / (float)kBins;
+        }
+        std::vector<SpaBins> part(n_chunks(refs.size()));
+        for_chunks(refs.size(), [&](size_t c, size_t i0, size_t i1) {
+            SpaBins& B = part[c];
+            for (int ax = 0; ax < 3; ax++) for (int b = 0; b < kBins; b++) { B.bb[ax][b].reset(); B.en[ax][b] = B.ex[ax][b] = 0; }
+            for (size_t i = i0; i < i1; i++) {
+                const Ref& r = refs[i];
+                for (int ax = 0; ax < 3; ax++) {
+                    if (!use[ax]) continue;
+                    int b0 = (int)((r.box.lo[ax] - lo[ax]) * scale[ax]), b1 = (int)((r.box.hi[ax] - lo[ax]) * scale[ax]);
+                    b0 = std::min(std::max(b0, 0), kBins - 1); b1 = std::min(std::max(b1, b0), kBins - 1);
+                    B.en[ax][b0]++; B.ex[ax][b1]++;
+                    if (b0 == b1) { B.bb[ax][b0].grow(r.box); continue; }
+                    for (int b = b0; b <= b1; b++) {
+                        const float plo = b == b0 ? -std::numeric_limits<float>::infinity() : lo[ax] + (float)b * width[ax];
+                        const float phi = b == b1 ? std::numeric_limits<float>::infinity() : lo[ax] + (float)(b + 1) * width[ax];
+                        Box cbx = clip.slab(r.face, ax, plo, phi);
+                        cbx.clip_to(r.box);
+                        if (cbx.valid()) B.bb[ax][b].grow(cbx);
+                    }
                 }
             }
+        });
+        SpaBins& T = part[0];
+        for (size_t c = 1; c < part.size(); c++)
+            for (int ax = 0; ax < 3; ax++) for (int b = 0; b < kBins; b++) { T.en[ax][b] += part[c].en[ax][b]; T.ex[ax][b] += part[c].ex[ax][b]; T.bb[ax][b].grow(part[c].bb[ax][b]); }
+        SpaSplit best; best.cost = std::numeric_limits<float>::infinity(); best.axis = -1; best.bin = 0; best.pos = 0.f; best.nl = best.nr = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            if (!use[ax]) continue;
+            const Box* bb = T.bb[ax];
             Box lb[kBins]; uint32_t lc[kBins];
             Box acc; acc.reset(); uint32_t c = 0;
-            for (int b = 0; b < kBins - 1; b++) { acc.grow(bb[b]); c += entry[b]; lb[b] = acc; lc[b] = c; }
+            for (int b = 0; b < kBins - 1; b++) { acc.grow(bb[b]); c += T.en[ax][b]; lb[b] = acc; lc[b] = c; }
             acc.reset(); c = 0;
             for (int b = kBins - 1; b > 0; b--) {
                 acc.grow(bb[b]);
-                c += exit_[b];
+                c += T.ex[ax][b];
                 if (!lc[b - 1] || !c) continue;
                 if (lc[b - 1] >= refs.size() || c >= refs.size()) continue;   // no progress on one side
                 const float cost = lb[b - 1].half_area() * (float)lc[b - 1] + acc.half_area() * (float)c;
-                if (cost < best.cost) { best.cost = cost; best.axis = ax; best.bin = b - 1; best.pos = lo + (float)b * width; best.nl = lc[b - 1]; best.nr = c; }
+                if (cost < best.cost) { best.cost = cost; best.axis = ax; best.bin = b - 1; best.pos = lo[ax] + (float)b * width[ax]; best.nl = lc[b - 1]; best.nr = c; }
             }
         }
         return best;
     }
 
-    void recurse(uint32_t left, std::vector<Ref>& L, std::vector<Ref>& R, size_t count) {
-        if (count >= kParallelMin && tasks_left.fetch_sub(1) > 0) {
-            auto fut = std::async(std::launch::async, [this, left, &L] { build(left, L); });
-            build(left + 1, R);
+    // per-chunk output of a partition pass, concatenated in chunk order afterwards
+    struct Piece { std::vector<Ref> L, R; Bounds bl, br; int64_t uncut = 0; };
+    void concat(std::vector<Piece>& pc, std::vector<Ref>& L, std::vector<Ref>& R, Bounds& bl, Bounds& br) {
+        std::vector<size_t> ol(pc.size() + 1, 0), orr(pc.size() + 1, 0);
+        bl.reset(); br.reset();
+        for (size_t c = 0; c < pc.size(); c++) { ol[c + 1] = ol[c] + pc[c].L.size(); orr[c + 1] = orr[c] + pc[c].R.size(); bl.grow(pc[c].bl); br.grow(pc[c].br); }
+        L.resize(ol.back()); R.resize(orr.back());
+        for_chunks(pc.size() * kChunk, [&](size_t c, size_t, size_t) {
+            if (c >= pc.size()) return;
+            std::copy(pc[c].L.begin(), pc[c].L.end(), L.begin() + (std::ptrdiff_t)ol[c]);
+            std::copy(pc[c].R.begin(), pc[c].R.end(), R.begin() + (std::ptrdiff_t)orr[c]);
+            std::vector<Ref>().swap(pc[c].L); std::vector<Ref>().swap(pc[c].R);
+        });
+    }
+
+    void recurse(uint32_t left, std::vector<Ref>& L, const Bounds& bl, std::vector<Ref>& R, const Bounds& br, size_t count) {
+        if (count >= kParallelMin && acquire(1) == 1) {
+            auto fut = std::async(std::launch::async, [this, left, &L, &bl] { build(left, L, bl); });
+            build(left + 1, R, br);
             fut.get();
-            tasks_left.fetch_add(1);
+            release(1);
         } else {
-            if (count >= kParallelMin) tasks_left.fetch_add(1);
-            build(left, L);
-            build(left + 1, R);
+            build(left, L, bl);
+            build(left + 1, R, br);
         }
     }
 
-    // consumes `refs`
-    void build(uint32_t ni, std::vector<Ref>& refs) {
+    // consumes `refs`; bd = bounds of the references and of their centroids
+    void build(uint32_t ni, std::vector<Ref>& refs, const Bounds& bd) {
         const size_t count = refs.size();
-        Box nb, cb; nb.reset(); cb.reset();
-        for (const Ref& r : refs) {
-            nb.grow(r.box);
-            const float c[3] = { centroid(r, 0), centroid(r, 1), centroid(r, 2) };
-            cb.grow_pt(c);
-        }
+        const Box& nb = bd.nb; const Box& cb = bd.cb;
         nodes[ni].box = nb;
         if (count <= max_leaf || failed) { make_leaf(ni, refs); std::vector<Ref>().swap(refs); return; }
 
@@ -240,102 +324,123 @@ struct Builder {
         }
 
         std::vector<Ref> L, R;
+        Bounds bl, br;
+        int64_t reserved = 0;
         if (spatial) {
-            // budget: one extra reference per straddler that is really cut
-            const int64_t extra = (int64_t)ss.nl + (int64_t)ss.nr - (int64_t)count;
-            if (budget.fetch_sub(extra) - extra < 0) { budget.fetch_add(extra); spatial = false; }
+            // budget: one extra reference per straddler that is really cut (reserved for all of them, the uncut ones are returned)
+            reserved = (int64_t)ss.nl + (int64_t)ss.nr - (int64_t)count;
+            if (budget.fetch_sub(reserved) - reserved < 0) { budget.fetch_add(reserved); reserved = 0; spatial = false; }
         }
         if (spatial) {
             const int ax = ss.axis; const float pos = ss.pos;
-            L.reserve(ss.nl); R.reserve(ss.nr);
-            Box lb, rb; lb.reset(); rb.reset();
-            std::vector<Ref> straddle;
-            for (const Ref& r : refs) {
-                if (r.box.hi[ax] <= pos) { L.push_back(r); lb.grow(r.box); }
-                else if (r.box.lo[ax] >= pos) { R.push_back(r); rb.grow(r.box); }
-                else straddle.push_back(r);
-            }
+            // pass 1: boxes and counts of the references that lie on one side
+            struct Side { Box lb, rb; uint64_t nl = 0, nr = 0; };
+            std::vector<Side> sd(n_chunks(count));
+            for_chunks(count, [&](size_t c, size_t i0, size_t i1) {
+                Side& S = sd[c]; S.lb.reset(); S.rb.reset();
+                for (size_t i = i0; i < i1; i++) {
+                    const Ref& r = refs[i];
+                    if (r.box.hi[ax] <= pos) { S.lb.grow(r.box); S.nl++; }
+                    else if (r.box.lo[ax] >= pos) { S.rb.grow(r.box); S.nr++; }
+                }
+            });
+            Box lb0, rb0; lb0.reset(); rb0.reset(); uint64_t nl0 = 0, nr0 = 0;
+            for (const Side& S : sd) { lb0.grow(S.lb); rb0.grow(S.rb); nl0 += S.nl; nr0 += S.nr; }
+            // pass 2: distribute; a straddler is cut, or kept whole on the cheaper side (reference unsplitting,
+            // Stich et al. §4.4, evaluated against the boxes of pass 1 so that the result does not depend on the order)
+            std::vector<Piece> pc(n_chunks(count));
+            for_chunks(count, [&](size_t c, size_t i0, size_t i1) {
+                Piece& P = pc[c]; P.bl.reset(); P.br.reset();
+                for (size_t i = i0; i < i1; i++) {
+                    const Ref& r = refs[i];
+                    if (r.box.hi[ax] <= pos) { P.L.push_back(r); grow_bounds(P.bl, r); continue; }
+                    if (r.box.lo[ax] >= pos) { P.R.push_back(r); grow_bounds(P.br, r); continue; }
+                    Ref a = r, b = r;
+                    a.box = clip.slab(r.face, ax, -std::numeric_limits<float>::infinity(), pos); a.box.clip_to(r.box);
+                    b.box = clip.slab(r.face, ax, pos, std::numeric_limits<float>::infinity()); b.box.clip_to(r.box);
+                    const bool va = a.box.valid(), vb = b.box.valid();
+                    int where = 0;      // 0 cut, 1 whole left, 2 whole right
+                    if (va && vb) {
+                        Box l1 = lb0; l1.grow(a.box); Box r1 = rb0; r1.grow(b.box);
+                        Box l2 = lb0; l2.grow(r.box); Box r2 = rb0; r2.grow(r.box);
+                        const float nl = (float)nl0, nr = (float)nr0;
+                        const float c_split = l1.half_area() * (nl + 1) + r1.half_area() * (nr + 1);
+                        const float c_left = l2.half_area() * (nl + 1) + rb0.half_area() * nr;
+                        const float c_right = lb0.half_area() * nl + r2.half_area() * (nr + 1);
+                        if (!(c_split <= c_left && c_split <= c_right)) where = c_left <= c_right ? 1 : 2;
+                    } else where = va ? 1 : 2;
+                    if (where == 0) { P.L.push_back(a); grow_bounds(P.bl, a); P.R.push_back(b); grow_bounds(P.br, b); }
+                    else if (where == 1) { P.L.push_back(r); grow_bounds(P.bl, r); P.uncut++; }
+                    else { P.R.push_back(r); grow_bounds(P.br, r); P.uncut++; }
+                }
+            });
             int64_t uncut = 0;
-            for (const Ref& r : straddle) {
-                Ref a = r, b = r;
-                a.box = clip.slab(r.face, ax, -std::numeric_limits<float>::infinity(), pos); a.box.clip_to(r.box);
-                b.box = clip.slab(r.face, ax, pos, std::numeric_limits<float>::infinity()); b.box.clip_to(r.box);
-                const bool va = a.box.valid(), vb = b.box.valid();
-                if (va && vb) {
-                    // reference unsplitting (Stich et al. §4.4): cut, or keep whole on the cheaper side
-                    Box l1 = lb; l1.grow(a.box); Box r1 = rb; r1.grow(b.box);
-                    Box l2 = lb; l2.grow(r.box); Box r2 = rb; r2.grow(r.box);
-                    const float nl = (float)L.size(), nr = (float)R.size();
-                    const float c_split = l1.half_area() * (nl + 1) + r1.half_area() * (nr + 1);
-                    const float c_left = l2.half_area() * (nl + 1) + rb.half_area() * nr;
-                    const float c_right = lb.half_area() * nl + r2.half_area() * (nr + 1);
-                    if (c_split <= c_left && c_split <= c_right) { L.push_back(a); R.push_back(b); lb = l1; rb = r1; }
-                    else if (c_left <= c_right) { L.push_back(r); lb = l2; uncut++; }
-                    else { R.push_back(r); rb = r2; uncut++; }
-                } else if (va) { a.box = r.box; L.push_back(a); lb.grow(a.box); uncut++; }
-                else { b.box = r.box; R.push_back(b); rb.grow(b.box); uncut++; }
-            }
+            for (const Piece& P : pc) uncut += P.uncut;
+            concat(pc, L, R, bl, br);
             if (uncut) budget.fetch_add(uncut);
-            if (L.empty() || R.empty() || L.size() >= count || R.size() >= count) { L.clear(); R.clear(); spatial = false; }
-            else n_spatial++;
+            if (L.empty() || R.empty() || L.size() >= count || R.size() >= count) {
+                budget.fetch_add(reserved - uncut);
+                L.clear(); R.clear(); spatial = false;
+            } else n_spatial++;
         }
         if (!spatial) {
-            size_t mid = 0;
-            if (os.axis >= 0) {
+            bool by_bin = os.axis >= 0;
+            if (by_bin) {
                 const float lo = cb.lo[os.axis], ext = cb.hi[os.axis] - cb.lo[os.axis];
                 const float scale = (float)kBins / ext;
-                size_t i = 0, j = count;
-                while (i < j) {
-                    int b = (int)((centroid(refs[i], os.axis) - lo) * scale);
-                    b = std::min(std::max(b, 0), kBins - 1);
-                    if (b <= os.bin) i++;
-                    else { j--; std::swap(refs[i], refs[j]); }
-                }
-                mid = i;
+                std::vector<Piece> pc(n_chunks(count));
+                for_chunks(count, [&](size_t c, size_t i0, size_t i1) {
+                    Piece& P = pc[c]; P.bl.reset(); P.br.reset();
+                    for (size_t i = i0; i < i1; i++) {
+                        const Ref& r = refs[i];
+                        int b = (int)((centroid(r, os.axis) - lo) * scale);
+                        b = std::min(std::max(b, 0), kBins - 1);
+                        if (b <= os.bin) { P.L.push_back(r); grow_bounds(P.bl, r); }
+                        else { P.R.push_back(r); grow_bounds(P.br, r); }
+                    }
+                });
+                concat(pc, L, R, bl, br);
+                if (L.empty() || R.empty()) { L.clear(); R.clear(); by_bin = false; }
             }
-            if (mid == 0 || mid == count) mid = count / 2;
-            L.assign(refs.begin(), refs.begin() + mid);
-            R.assign(refs.begin() + mid, refs.end());
+            if (!by_bin) {      // all centroids in one bin: halve the list
+                const size_t mid = count / 2;
+                L.assign(refs.begin(), refs.begin() + (std::ptrdiff_t)mid);
+                R.assign(refs.begin() + (std::ptrdiff_t)mid, refs.end());
+                bl.reset(); br.reset();
+                for (const Ref& r : L) grow_bounds(bl, r);
+                for (const Ref& r : R) grow_bounds(br, r);
+            }
         }
         std::vector<Ref>().swap(refs);   // free before descending
 
         const uint32_t left = next_node.fetch_add(2);
         if ((size_t)left + 2 > node_cap) { failed = true; nodes[ni].left = 0; nodes[ni].count = 1; return; }
         nodes[ni].left = left; nodes[ni].count = 0;
-        recurse(left, L, R, count);
+        recurse(left, L, bl, R, br, count);
     }
 };
 
+// BVH2 -> BVH4: a 4-wide node takes the two children of a binary node and keeps expanding the inner candidate of
+// largest area until it holds four.  Two passes so that the (10M-triangle) output can be written in parallel:
+// measure() sizes every 4-wide subtree, emit() writes nodes and leaf triangle records at the offsets that follow
+// from the sizes.  Layout: the inner children of a node are consecutive, their own descendants follow child by
+// child; the triangle records of a node's leaf children come first, then those of its inner children's subtrees.
 struct Collapser {
     const Node2* n2;
     const uint32_t* leaf_faces;
     Bvh4& out;
     const float* verts; const uint32_t* faces; const uint32_t* fobj;
     float inflate;
-    double sah = 0.0;
+    std::atomic<int> tasks_left{0};
+    std::unique_ptr<uint32_t[]> n4, nt;     // per BVH2 index, valid where a 4-wide node is rooted: nodes / triangle records of its subtree
 
-    uint32_t emit_leaf(const Node2& n) {
-        const uint32_t first = (uint32_t)out.tris.size();
-        for (uint32_t i = 0; i < n.count; i++) {
-            const uint32_t f = leaf_faces[n.left + i];
-            const float* a = verts + 3 * (size_t)faces[3 * (size_t)f + 0];
-            const float* b = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
-            const float* c = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
-            TriRec t;
-            for (int k = 0; k < 3; k++) { t.v0[k] = a[k]; t.e1[k] = b[k] - a[k]; t.e2[k] = c[k] - a[k]; }
-            t.face = f; t.object = fobj ? fobj[f] : 0u; t.pad = 0;
-            out.tris.push_back(t);
-        }
-        return kLeafFlag | ((n.count - 1) << 28) | first;
-    }
+    struct M { uint32_t n4 = 0, nt = 0, depth = 0, need = 0; double sah = 0.0; };
 
-    // returns {depth, stack_need} of the subtree rooted at BVH4 node `self`
-    std::pair<uint32_t, uint32_t> collapse(uint32_t self, uint32_t n2_idx) {
-        // gather up to 4 BVH2 nodes: expand the inner candidate of largest area
-        uint32_t cand[4]; int nc = 0;
+    int gather(uint32_t n2_idx, uint32_t cand[4]) const {
+        int nc = 0;
         const Node2& root = n2[n2_idx];
-        if (root.count) { cand[nc++] = n2_idx; }
-        else { cand[nc++] = root.left; cand[nc++] = root.left + 1; }
+        if (root.count) { cand[nc++] = n2_idx; return nc; }
+        cand[nc++] = root.left; cand[nc++] = root.left + 1;
         while (nc < 4) {
             int pick = -1; float best = -1.f;
             for (int i = 0; i < nc; i++) {
@@ -347,6 +452,51 @@ struct Collapser {
             const uint32_t l = n2[cand[pick]].left;
             cand[pick] = l; cand[nc++] = l + 1;
         }
+        return nc;
+    }
+    bool take_thread() { int cur = tasks_left.load(); while (cur > 0) { if (tasks_left.compare_exchange_weak(cur, cur - 1)) return true; } return false; }
+
+    M measure(uint32_t n2_idx, int level) {
+        uint32_t cand[4];
+        const int nc = gather(n2_idx, cand);
+        M m; m.n4 = 1;
+        M sub[4]; std::future<M> fut[4]; bool async_[4] = { false, false, false, false };
+        for (int i = 0; i < nc; i++) {
+            const Node2& c = n2[cand[i]];
+            if (c.count) { m.nt += c.count; m.sah += (double)c.box.half_area() * c.count; continue; }
+            m.sah += (double)c.box.half_area();
+            if (level < 4 && take_thread()) { async_[i] = true; fut[i] = std::async(std::launch::async, [this, ci = cand[i], level] { return measure(ci, level + 1); }); }
+            else sub[i] = measure(cand[i], level + 1);
+        }
+        for (int i = 0; i < nc; i++) {
+            if (n2[cand[i]].count) continue;
+            if (async_[i]) { sub[i] = fut[i].get(); tasks_left.fetch_add(1); }
+            m.n4 += sub[i].n4; m.nt += sub[i].nt; m.sah += sub[i].sah;
+            m.depth = std::max(m.depth, sub[i].depth); m.need = std::max(m.need, sub[i].need);
+        }
+        m.depth += 1; m.need += (uint32_t)(nc > 0 ? nc - 1 : 0);
+        n4[n2_idx] = m.n4; nt[n2_idx] = m.nt;
+        return m;
+    }
+
+    void emit_leaf(const Node2& n, uint32_t first) {
+        for (uint32_t i = 0; i < n.count; i++) {
+            const uint32_t f = leaf_faces[n.left + i];
+            const float* a = verts + 3 * (size_t)faces[3 * (size_t)f + 0];
+            const float* b = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
+            const float* c = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
+            TriRec t;
+            for (int k = 0; k < 3; k++) { t.v0[k] = a[k]; t.e1[k] = b[k] - a[k]; t.e2[k] = c[k] - a[k]; }
+            t.face = f; t.object = fobj ? fobj[f] : 0u; t.pad = 0;
+            out.tris[first + i] = t;
+        }
+    }
+
+    // writes 4-wide node `self` (rooted at BVH2 node n2_idx); its descendants go to nodes [desc_base, ...), the
+    // triangle records of its subtree to [tri_base, ...)
+    void emit(uint32_t self, uint32_t n2_idx, uint32_t desc_base, uint32_t tri_base, int level) {
+        uint32_t cand[4];
+        const int nc = gather(n2_idx, cand);
         Node4 nd;
         // empty slot: a degenerate box at +3e38 -- the slab test then yields t = +-huge
         // on every axis and can never pass (inverted +-inf boxes would: min/max reorder them)
@@ -354,30 +504,36 @@ struct Collapser {
             for (int k = 0; k < 3; k++) nd.c[i].lo[k] = nd.c[i].hi[k] = kEmptyCoord;
             nd.c[i].ref = kEmptyRef; nd.c[i].pad = 0;
         }
-        uint32_t depth = 0, need = 0;
-        uint32_t inner_self[4];
-        for (int i = 0; i < nc; i++) {
+        int n_inner = 0;
+        for (int i = 0; i < nc; i++) n_inner += n2[cand[i]].count ? 0 : 1;
+        uint32_t child_self = desc_base, child_desc = desc_base + (uint32_t)n_inner, tri = tri_base;
+        uint32_t cs[4], cd[4], ct[4];
+        for (int i = 0; i < nc; i++) {       // leaf children first in the triangle array
             const Node2& c = n2[cand[i]];
             for (int k = 0; k < 3; k++) { nd.c[i].lo[k] = c.box.lo[k] - inflate; nd.c[i].hi[k] = c.box.hi[k] + inflate; }
             if (c.count) {
-                nd.c[i].ref = emit_leaf(c);
-                sah += (double)c.box.half_area() * c.count;
-                inner_self[i] = 0xFFFFFFFFu;
-            } else {
-                inner_self[i] = (uint32_t)out.nodes.size();
-                out.nodes.emplace_back();
-                nd.c[i].ref = inner_self[i];
-                sah += (double)c.box.half_area();
+                emit_leaf(c, tri);
+                nd.c[i].ref = kLeafFlag | ((c.count - 1) << 28) | tri;
+                tri += c.count;
             }
         }
-        out.nodes[self] = nd;
         for (int i = 0; i < nc; i++) {
-            if (inner_self[i] == 0xFFFFFFFFu) continue;
-            auto r = collapse(inner_self[i], cand[i]);
-            depth = std::max(depth, r.first);
-            need = std::max(need, r.second);
+            const Node2& c = n2[cand[i]];
+            if (c.count) continue;
+            cs[i] = child_self++; cd[i] = child_desc; ct[i] = tri;
+            nd.c[i].ref = cs[i];
+            child_desc += n4[cand[i]] - 1; tri += nt[cand[i]];
         }
-        return { depth + 1, need + (uint32_t)(nc > 0 ? nc - 1 : 0) };
+        out.nodes[self] = nd;
+        std::future<void> fut[4]; bool async_[4] = { false, false, false, false };
+        for (int i = 0; i < nc; i++) {
+            if (n2[cand[i]].count) continue;
+            if (level < 4 && n4[cand[i]] > 4096 && take_thread()) {
+                async_[i] = true;
+                fut[i] = std::async(std::launch::async, [this, a = cs[i], b = cand[i], c2 = cd[i], d = ct[i], level] { emit(a, b, c2, d, level + 1); });
+            } else emit(cs[i], cand[i], cd[i], ct[i], level + 1);
+        }
+        for (int i = 0; i < nc; i++) if (async_[i]) { fut[i].get(); tasks_left.fetch_add(1); }
     }
 };
 
@@ -428,13 +584,18 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
     // that culling never removes a triangle the exact-order brute force accepts
     out.inflate = 2e-5f * std::max(ext, mag) + 1e-6f;
 
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    // more than ~32-64 threads lose to allocator and page-fault contention (10M triangles on a 256-thread host:
+    // 36.6 s with 1 thread, 9.7 s with 8, 6.0 s with 32 or 64, 18.8 s with 256)
+    if (n_threads <= 0) n_threads = (int)std::min(48u, std::max(1u, std::thread::hardware_concurrency()));
+    const bool verbose = getenv("RR_BVH_VERBOSE") != nullptr;
+    auto lap = [&](const char* what) { if (verbose) fprintf(stderr, "[rr bvh] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); };
+    lap("validated, references made");
     const double budget_f = std::max(0.0, (double)opt.ref_budget) * (double)nf;
     const size_t max_refs = std::min<size_t>(nf + (size_t)budget_f + 16, (size_t)1 << 28);
     const size_t node_cap = 2 * max_refs + 1;
     std::unique_ptr<Node2[]> n2(new Node2[node_cap]);                 // default-initialised: pages are touched on use only
     std::unique_ptr<uint32_t[]> leaf_faces(new uint32_t[max_refs]);
-    uint64_t n_leaf_refs = 0;
+    uint64_t n_leaf_refs = 0; uint32_t n_nodes_used = 1;
     {
         Builder b{ Clipper{ verts, faces } };
         b.nodes = n2.get(); b.node_cap = node_cap;
@@ -443,23 +604,31 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
         b.tasks_left = n_threads - 1;
         b.root_area = scene.half_area(); b.alpha = opt.sbvh_alpha;
         b.max_leaf = kMaxLeafTris;
-        b.build(0, refs);
+        Builder::Bounds bd; bd.reset();
+        for (const Ref& r : refs) Builder::grow_bounds(bd, r);
+        b.build(0, refs, bd);
         if (b.failed) { err = "rr_set_mesh: internal error (reference budget exceeded)"; return false; }
         n_leaf_refs = b.next_leaf.load();
+        n_nodes_used = b.next_node.load();
         out.spatial_splits = b.n_spatial.load();
     }
 
-    out.nodes.reserve(n_leaf_refs / 2 + 16);
-    out.tris.reserve(n_leaf_refs);
-    out.nodes.emplace_back();
+    lap("binary tree built");
     Collapser c{ n2.get(), leaf_faces.get(), out, verts, faces, face_object, out.inflate };
-    auto r = c.collapse(0, 0);
-    out.depth = r.first;
-    out.stack_need = r.second;
+    c.tasks_left = n_threads - 1;
+    const size_t n_bin = (size_t)n_nodes_used;
+    c.n4.reset(new uint32_t[n_bin]); c.nt.reset(new uint32_t[n_bin]);
+    const Collapser::M m = c.measure(0, 0);
+    if (m.nt != n_leaf_refs) { err = "rr_set_mesh: internal error (leaf triangle count)"; return false; }
+    out.nodes.resize(m.n4);
+    out.tris.resize(m.nt);
+    c.emit(0, 0, 1, 0, 0);
+    lap("collapsed to 4-wide");
+    out.depth = m.depth;
+    out.stack_need = m.need;
     const float ra = scene.half_area();
-    out.sah_cost = ra > 0.f ? c.sah / ra : 0.0;
+    out.sah_cost = ra > 0.f ? m.sah / ra : 0.0;
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (out.tris.size() != n_leaf_refs) { err = "rr_set_mesh: internal error (leaf triangle count)"; return false; }
     return true;
 }
 
