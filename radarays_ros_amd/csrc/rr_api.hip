@@ -24,7 +24,7 @@ void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_c
                         int n_loc = 0, size_t block_stride = 0, int n_frames = 1, size_t frame_stride = 0);
 void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cells, int scroll, hipStream_t s);
 bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object,
-                    Node4** d_nodes_out, size_t* n_nodes_out, TriRec** d_tris_out,
+                    Node4** d_nodes_out, size_t* n_nodes_out, TriRec** d_tris_out, size_t* n_tris_out,
                     uint32_t* depth_out, uint32_t* stack_need_out, float* inflate_out,
                     std::string& err, hipStream_t stream);
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
@@ -674,21 +674,21 @@ int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* fa
     if (!verts || !faces) return fail(c, -4, "rr_set_mesh_gpu: null vertex/face pointer");
     RR_HIP(c, hipSetDevice(c->device));
     RR_HIP(c, hipDeviceSynchronize());
-    Node4* dn = nullptr; TriRec* dt = nullptr; size_t nn = 0; uint32_t depth = 0, need = 0; float inflate = 0.f;
+    Node4* dn = nullptr; TriRec* dt = nullptr; size_t nn = 0, nt = 0; uint32_t depth = 0, need = 0; float inflate = 0.f;
     std::string err;
-    if (!build_bvh4_gpu(verts, nv, faces, nf, face_object_id, &dn, &nn, &dt, &depth, &need, &inflate, err, c->stream))
+    if (!build_bvh4_gpu(verts, nv, faces, nf, face_object_id, &dn, &nn, &dt, &nt, &depth, &need, &inflate, err, c->stream))
         return fail(c, -4, err);
     {
         // the builder hands over two arrays: move them into the one allocation the traversal addresses
-        int rc = check_bvh_size(c, nn, nf);
+        int rc = check_bvh_size(c, nn, nt);
         hipError_t e = hipSuccess;
         if (!rc) {
             c->have_mesh = false;           // see rr_set_mesh: no mesh while the tree is being replaced
             for (Lane& L : c->lanes) L.buf_seg = 0;
             c->tri_base4 = (uint32_t)(nn * 8);
-            e = c->d_bvh.ensure(nn * 8 + (nf + 4) * 3);
+            e = c->d_bvh.ensure(nn * 8 + (nt + 4) * 3);
             if (e == hipSuccess) e = hipMemcpy(c->d_bvh.p, dn, nn * sizeof(Node4), hipMemcpyDeviceToDevice);
-            if (e == hipSuccess) e = hipMemcpy(c->d_bvh.p + c->tri_base4, dt, nf * sizeof(TriRec), hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c->d_bvh.p + c->tri_base4, dt, nt * sizeof(TriRec), hipMemcpyDeviceToDevice);
         }
         (void)hipFree(dn); (void)hipFree(dt);
         if (rc) return rc;
@@ -697,7 +697,7 @@ int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* fa
         RR_HIP(c, hipGetLastError());
         RR_HIP(c, hipDeviceSynchronize());
     }
-    c->n_nodes = nn; c->n_tris = nf; c->depth = depth; c->stack_need = need;
+    c->n_nodes = nn; c->n_tris = nt; c->depth = depth; c->stack_need = need;
     c->have_mesh = true;
     for (Lane& L : c->lanes) L.buf_seg = 0;
     return 0;

@@ -2,7 +2,11 @@
 // rm::import_embree_map's Embree build, src/radar_simulator.cpp:149, for maps that must load
 // in milliseconds instead of seconds).
 //
-//   1. per-face bounds + 63-bit Morton code of the centroid          k_prim
+//   0. early split clipping (Ernst & Greiner 2007): a face much larger than its neighbours is cut along a grid of
+//      cell size L into references {clipped box, face}; L is the smallest cell that keeps the reference count
+//      within +25 % (bisection over a counting kernel).  Without it one 15 m building face inflates every
+//      Morton-neighbourhood of 0.2 m terrain triangles it is sorted into.                 k_split<false/true>
+//   1. per-reference bounds + 63-bit Morton code of the centroid     k_prim
 //   2. rocprim radix sort of (code, face)                             rocprim::radix_sort_pairs
 //   3. Karras 2012 binary radix tree over the sorted codes           k_karras
 //   4. bottom-up bounds + subtree sizes (one atomic ticket per node)  k_refit
@@ -14,8 +18,10 @@
 // but the nearest hit is defined order-independently (min over (t, face id)), so images are
 // BIT-IDENTICAL whichever builder made the tree.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -42,19 +48,102 @@ __device__ inline unsigned long long expand21(unsigned long long v)
     return v;
 }
 
-__global__ void k_prim(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t nf,
-                       float3 slo, float3 sinv, Box6* __restrict__ pbox, unsigned long long* __restrict__ keys,
-                       uint32_t* __restrict__ vals)
+// bounds of (triangle clipped to the axis-aligned box [clo, chi]), Sutherland-Hodgman in f32; false if empty.
+// The result is rounded outwards by one ulp and intersected with the cell, so the parts of a face cover it.
+__device__ inline bool clip_tri_box(const float* a, const float* b, const float* c, const float* clo, const float* chi, Box6& out)
+{
+    float p[10][3], q[10][3];
+    int n = 3;
+    for (int k = 0; k < 3; k++) { p[0][k] = a[k]; p[1][k] = b[k]; p[2][k] = c[k]; }
+    for (int axis = 0; axis < 3 && n > 0; axis++)
+        for (int side = 0; side < 2 && n > 0; side++) {
+            const float plane = side == 0 ? clo[axis] : chi[axis];
+            int m = 0;
+            for (int i = 0; i < n; i++) {
+                const float* u = p[i]; const float* v = p[(i + 1) % n];
+                const bool inu = side == 0 ? u[axis] >= plane : u[axis] <= plane;
+                const bool inv = side == 0 ? v[axis] >= plane : v[axis] <= plane;
+                if (inu) { q[m][0] = u[0]; q[m][1] = u[1]; q[m][2] = u[2]; m++; }
+                if (inu != inv) {
+                    const float t = (plane - u[axis]) / (v[axis] - u[axis]);
+                    for (int k = 0; k < 3; k++) q[m][k] = u[k] + t * (v[k] - u[k]);
+                    q[m][axis] = plane;
+                    m++;
+                }
+            }
+            n = m;
+            for (int i = 0; i < n; i++) { p[i][0] = q[i][0]; p[i][1] = q[i][1]; p[i][2] = q[i][2]; }
+        }
+    if (n == 0) return false;
+    for (int k = 0; k < 3; k++) { out.lo[k] = 3.0e38f; out.hi[k] = -3.0e38f; }
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) { out.lo[k] = fminf(out.lo[k], p[i][k]); out.hi[k] = fmaxf(out.hi[k], p[i][k]); }
+    for (int k = 0; k < 3; k++) {
+        const float e = 1e-6f * (fabsf(out.lo[k]) + fabsf(out.hi[k])) + 1e-30f;    // interpolation error of the cut points
+        out.lo[k] = fmaxf(out.lo[k] - e, clo[k] - e); out.hi[k] = fminf(out.hi[k] + e, chi[k] + e);
+    }
+    return true;
+}
+
+constexpr int kMaxCellsPerAxis = 24;     // a face is cut into at most 24 cells per axis (its own coarser grid beyond that)
+
+// EMIT = false: count[f] = references face f yields for cell size L; EMIT = true: write them at offset[f]
+template <bool EMIT>
+__global__ void k_split(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t nf, float L, float3 slo,
+                        uint32_t* __restrict__ count, const uint32_t* __restrict__ offset,
+                        Box6* __restrict__ rbox, uint32_t* __restrict__ rface)
 {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
-    Box6 b;
-    for (int k = 0; k < 3; k++) { b.lo[k] = 3.0e38f; b.hi[k] = -3.0e38f; }
-    for (int v = 0; v < 3; v++) {
-        const float* p = verts + 3 * (size_t)faces[3 * (size_t)f + v];
-        for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], p[k]); b.hi[k] = fmaxf(b.hi[k], p[k]); }
+    const float* a = verts + 3 * (size_t)faces[3 * (size_t)f + 0];
+    const float* b = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
+    const float* c = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
+    Box6 bb;
+    for (int k = 0; k < 3; k++) { bb.lo[k] = fminf(a[k], fminf(b[k], c[k])); bb.hi[k] = fmaxf(a[k], fmaxf(b[k], c[k])); }
+    int i0[3], nc[3]; float cell[3];
+    const float org[3] = { slo.x, slo.y, slo.z };       // the grid starts at the scene's lower corner
+    long total = 1;
+    for (int k = 0; k < 3; k++) {
+        cell[k] = L;
+        const float ext = bb.hi[k] - bb.lo[k];
+        if (ext > L * (float)kMaxCellsPerAxis) cell[k] = ext / (float)kMaxCellsPerAxis;
+        i0[k] = (int)floorf((bb.lo[k] - org[k]) / cell[k]);
+        nc[k] = (int)floorf((bb.hi[k] - org[k]) / cell[k]) - i0[k] + 1;
+        nc[k] = max(1, min(nc[k], kMaxCellsPerAxis + 1));
+        total *= nc[k];
     }
-    pbox[f] = b;
+    uint32_t n = 0;
+    const uint32_t base = EMIT ? offset[f] : 0u;
+    if (total == 1) {
+        if (EMIT) { rbox[base] = bb; rface[base] = f; }
+        n = 1;
+    } else {
+        for (int z = 0; z < nc[2]; z++) for (int y = 0; y < nc[1]; y++) for (int x = 0; x < nc[0]; x++) {
+            const int id[3] = { x, y, z };
+            float clo[3], chi[3];
+            for (int k = 0; k < 3; k++) {
+                clo[k] = id[k] == 0 ? bb.lo[k] : org[k] + (float)(i0[k] + id[k]) * cell[k];
+                chi[k] = id[k] == nc[k] - 1 ? bb.hi[k] : org[k] + (float)(i0[k] + id[k] + 1) * cell[k];
+            }
+            Box6 part;
+            if (!clip_tri_box(a, b, c, clo, chi, part)) continue;
+            if (EMIT) { rbox[base + n] = part; rface[base + n] = f; }
+            n++;
+        }
+        if (n == 0) {      // numerically empty everywhere (degenerate face): keep it whole
+            if (EMIT) { rbox[base] = bb; rface[base] = f; }
+            n = 1;
+        }
+    }
+    if (!EMIT) count[f] = n;
+}
+
+__global__ void k_prim(uint32_t nf, float3 slo, float3 sinv, const Box6* __restrict__ pbox,
+                       unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    const Box6 b = pbox[f];
     const float cx = (0.5f * (b.lo[0] + b.hi[0]) - slo.x) * sinv.x;
     const float cy = (0.5f * (b.lo[1] + b.hi[1]) - slo.y) * sinv.y;
     const float cz = (0.5f * (b.lo[2] + b.hi[2]) - slo.z) * sinv.z;
@@ -186,11 +275,11 @@ __global__ void k_collapse(const RNode* __restrict__ rn, const RInfo* __restrict
 }
 
 __global__ void k_tris(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const uint32_t* __restrict__ fobj,
-                       const uint32_t* __restrict__ sorted, uint32_t nf, TriRec* __restrict__ tris)
+                       const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ rface, uint32_t n_refs, TriRec* __restrict__ tris)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nf) return;
-    const uint32_t f = sorted[p];
+    if (p >= n_refs) return;
+    const uint32_t f = rface[sorted[p]];
     const float* a = verts + 3 * (size_t)faces[3 * (size_t)f + 0];
     const float* b = verts + 3 * (size_t)faces[3 * (size_t)f + 1];
     const float* c = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
@@ -213,11 +302,11 @@ struct Tmp {
 
 // Builds into caller-owned device arrays (allocated here with hipMalloc; the caller frees them).
 bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object,
-                    Node4** d_nodes_out, size_t* n_nodes_out, TriRec** d_tris_out,
+                    Node4** d_nodes_out, size_t* n_nodes_out, TriRec** d_tris_out, size_t* n_tris_out,
                     uint32_t* depth_out, uint32_t* stack_need_out, float* inflate_out,
                     std::string& err, hipStream_t stream)
 {
-    *d_nodes_out = nullptr; *d_tris_out = nullptr; *n_nodes_out = 0;
+    *d_nodes_out = nullptr; *d_tris_out = nullptr; *n_nodes_out = 0; *n_tris_out = 0;
     if (nf == 0 || nf >= (1u << 28)) { err = "gpu builder: triangle count must be in [1, 2^28)"; return false; }
     for (size_t i = 0; i < 3 * nf; i++) if (faces[i] >= nv) { err = "rr_set_mesh: face index out of range"; return false; }
     float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
@@ -232,40 +321,77 @@ bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t
     const float3 slo = make_float3(lo[0], lo[1], lo[2]);
     const float3 sinv = make_float3(hi[0] > lo[0] ? 1.0f / (hi[0] - lo[0]) : 0.f, hi[1] > lo[1] ? 1.0f / (hi[1] - lo[1]) : 0.f,
                                     hi[2] > lo[2] ? 1.0f / (hi[2] - lo[2]) : 0.f);
-    const int n = (int)nf;
     const int TB = 256;
+    const int nfb = (int)((nf + TB - 1) / TB);
 
-    Tmp<float> d_verts; Tmp<uint32_t> d_faces, d_fobj, d_vals_in, d_vals; Tmp<Box6> d_pbox;
+    Tmp<float> d_verts; Tmp<uint32_t> d_faces, d_fobj, d_vals_in, d_vals, d_count, d_offset, d_rface; Tmp<Box6> d_pbox;
     Tmp<unsigned long long> d_keys_in, d_keys; Tmp<RNode> d_rn; Tmp<RInfo> d_info; Tmp<unsigned int> d_ticket;
     Tmp<Work> d_wa, d_wb; Tmp<uint32_t> d_cnt;    // cnt[0] = n_out, cnt[1] = n_nodes4, cnt[2] = max_need
-    Tmp<char> d_sort_tmp;
+    Tmp<char> d_sort_tmp, d_scan_tmp;
     LB_HIP(d_verts.alloc(3 * nv)); LB_HIP(d_faces.alloc(3 * nf));
     if (face_object) LB_HIP(d_fobj.alloc(nf));
-    LB_HIP(d_vals_in.alloc(nf)); LB_HIP(d_vals.alloc(nf)); LB_HIP(d_pbox.alloc(nf));
-    LB_HIP(d_keys_in.alloc(nf)); LB_HIP(d_keys.alloc(nf));
-    LB_HIP(d_rn.alloc(2 * nf)); LB_HIP(d_info.alloc(2 * nf)); LB_HIP(d_ticket.alloc(nf));
-    LB_HIP(d_wa.alloc(nf)); LB_HIP(d_wb.alloc(nf)); LB_HIP(d_cnt.alloc(4));
+    LB_HIP(d_count.alloc(nf)); LB_HIP(d_offset.alloc(nf));
     LB_HIP(hipMemcpyAsync(d_verts.p, verts, 3 * nv * sizeof(float), hipMemcpyHostToDevice, stream));
     LB_HIP(hipMemcpyAsync(d_faces.p, faces, 3 * nf * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     if (face_object) LB_HIP(hipMemcpyAsync(d_fobj.p, face_object, nf * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 
-    hipLaunchKernelGGL(k_prim, dim3((n + TB - 1) / TB), dim3(TB), 0, stream, d_verts.p, d_faces.p, (uint32_t)nf, slo, sinv,
-                       d_pbox.p, d_keys_in.p, d_vals_in.p);
-    size_t tmp_bytes = 0;
-    LB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_in.p, d_keys.p, d_vals_in.p, d_vals.p, nf, 0, 63, stream));
-    LB_HIP(d_sort_tmp.alloc(tmp_bytes));
-    LB_HIP(rocprim::radix_sort_pairs(d_sort_tmp.p, tmp_bytes, d_keys_in.p, d_keys.p, d_vals_in.p, d_vals.p, nf, 0, 63, stream));
+    // ---- 0. early split clipping: the smallest grid cell L that keeps the references within +25 % ----------------
+    size_t scan_bytes = 0;
+    LB_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_count.p, d_offset.p, 0u, nf, rocprim::plus<uint32_t>(), stream));
+    LB_HIP(d_scan_tmp.alloc(scan_bytes));
+    auto refs_for = [&](float L, size_t& total) -> bool {
+        hipLaunchKernelGGL((k_split<false>), dim3(nfb), dim3(TB), 0, stream, d_verts.p, d_faces.p, (uint32_t)nf, L, slo, d_count.p,
+                           (const uint32_t*)nullptr, (Box6*)nullptr, (uint32_t*)nullptr);
+        if (rocprim::exclusive_scan(d_scan_tmp.p, scan_bytes, d_count.p, d_offset.p, 0u, nf, rocprim::plus<uint32_t>(), stream) != hipSuccess) return false;
+        uint32_t last_off = 0, last_cnt = 0;
+        if (hipMemcpyAsync(&last_off, d_offset.p + (nf - 1), 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+        if (hipMemcpyAsync(&last_cnt, d_count.p + (nf - 1), 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+        if (hipStreamSynchronize(stream) != hipSuccess) return false;
+        total = (size_t)last_off + last_cnt;
+        return true;
+    };
+    const size_t ref_limit = std::min<size_t>(nf + nf / 4 + 64, ((size_t)1 << 28) - 8);
+    float L = std::max(ext, 1e-20f) * 2.0f;          // one cell holds the scene: no face is cut
+    size_t n_refs = nf;
+    if (!getenv("RR_LBVH_NO_SPLIT") && ext > 0.f) {
+        float lo_l = L / 65536.0f, hi_l = L;        // refs(hi_l) <= limit always; refs grows as L shrinks
+        for (int it = 0; it < 14; it++) {
+            const float mid = std::sqrt(lo_l * hi_l);
+            size_t tot = 0;
+            if (!refs_for(mid, tot)) { err = "gpu builder: split counting failed"; return false; }
+            if (tot <= ref_limit) hi_l = mid; else lo_l = mid;
+        }
+        L = hi_l;
+    }
+    if (!refs_for(L, n_refs)) { err = "gpu builder: split counting failed"; return false; }
+    if (n_refs < nf || n_refs > ref_limit + nf) { err = "gpu builder: internal error (reference count)"; return false; }
+    const int n = (int)n_refs;
+    LB_HIP(d_pbox.alloc(n_refs)); LB_HIP(d_rface.alloc(n_refs));
+    hipLaunchKernelGGL((k_split<true>), dim3(nfb), dim3(TB), 0, stream, d_verts.p, d_faces.p, (uint32_t)nf, L, slo, (uint32_t*)nullptr,
+                       (const uint32_t*)d_offset.p, d_pbox.p, d_rface.p);
 
-    LB_HIP(hipMemsetAsync(d_ticket.p, 0, nf * sizeof(unsigned int), stream));
+    LB_HIP(d_vals_in.alloc(n_refs)); LB_HIP(d_vals.alloc(n_refs));
+    LB_HIP(d_keys_in.alloc(n_refs)); LB_HIP(d_keys.alloc(n_refs));
+    LB_HIP(d_rn.alloc(2 * n_refs)); LB_HIP(d_info.alloc(2 * n_refs)); LB_HIP(d_ticket.alloc(n_refs));
+    LB_HIP(d_wa.alloc(n_refs)); LB_HIP(d_wb.alloc(n_refs)); LB_HIP(d_cnt.alloc(4));
+
+    hipLaunchKernelGGL(k_prim, dim3((n + TB - 1) / TB), dim3(TB), 0, stream, (uint32_t)n_refs, slo, sinv,
+                       (const Box6*)d_pbox.p, d_keys_in.p, d_vals_in.p);
+    size_t tmp_bytes = 0;
+    LB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_in.p, d_keys.p, d_vals_in.p, d_vals.p, n_refs, 0, 63, stream));
+    LB_HIP(d_sort_tmp.alloc(tmp_bytes));
+    LB_HIP(rocprim::radix_sort_pairs(d_sort_tmp.p, tmp_bytes, d_keys_in.p, d_keys.p, d_vals_in.p, d_vals.p, n_refs, 0, 63, stream));
+
+    LB_HIP(hipMemsetAsync(d_ticket.p, 0, n_refs * sizeof(unsigned int), stream));
     if (n > 1) hipLaunchKernelGGL(k_karras, dim3((n - 1 + TB - 1) / TB), dim3(TB), 0, stream, d_keys.p, n, d_rn.p);
     hipLaunchKernelGGL(k_refit, dim3((n + TB - 1) / TB), dim3(TB), 0, stream, d_rn.p, d_pbox.p, d_vals.p, n, d_info.p, d_ticket.p);
 
     // output arrays: at most one 4-wide node per inner radix node (+ root)
     Node4* d_nodes = nullptr; TriRec* d_tris = nullptr;
-    LB_HIP(hipMalloc((void**)&d_nodes, (nf + 1) * sizeof(Node4)));
-    if (hipMalloc((void**)&d_tris, (nf + 4) * sizeof(TriRec)) != hipSuccess) { (void)hipFree(d_nodes); err = "hipMalloc(tris) failed"; return false; }
+    LB_HIP(hipMalloc((void**)&d_nodes, (n_refs + 1) * sizeof(Node4)));
+    if (hipMalloc((void**)&d_tris, (n_refs + 4) * sizeof(TriRec)) != hipSuccess) { (void)hipFree(d_nodes); err = "hipMalloc(tris) failed"; return false; }
     hipLaunchKernelGGL(k_tris, dim3((n + TB - 1) / TB), dim3(TB), 0, stream, d_verts.p, d_faces.p, face_object ? d_fobj.p : nullptr,
-                       d_vals.p, (uint32_t)nf, d_tris);
+                       d_vals.p, (const uint32_t*)d_rface.p, (uint32_t)n_refs, d_tris);
 
     const uint32_t root = (n == 1) ? 0u : 0u;   // radix root is inner node 0; a single triangle is leaf index n-1 = 0
     Work w0; w0.rnode = root; w0.node4 = 0; w0.acc = 0;
@@ -293,7 +419,7 @@ bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t
         err = "gpu BVH build failed";
         return false;
     }
-    *d_nodes_out = d_nodes; *d_tris_out = d_tris; *n_nodes_out = cnt[1];
+    *d_nodes_out = d_nodes; *d_tris_out = d_tris; *n_nodes_out = cnt[1]; *n_tris_out = n_refs;
     *depth_out = depth; *stack_need_out = cnt[2]; *inflate_out = inflate;
     return true;
 }

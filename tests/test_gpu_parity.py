@@ -519,7 +519,7 @@ def test_gpu_bvh_builder_gives_identical_images(native_lib):
         t0, f0 = c.debug_trace(o, d)
         c.set_mesh(s["verts"], s["faces"], s["face_object_id"], builder="gpu")
         info = c.bvh_info()
-        assert info["n_tris"] == len(s["faces"]) and info["depth"] >= 1
+        assert len(s["faces"]) <= info["n_tris"] <= 2 * len(s["faces"]) + 64 and info["depth"] >= 1   # + the parts of split faces
         b8, bf, bst = c.simulate(pose, want_f32=True)
         t1, f1 = c.debug_trace(o, d)
         assert np.array_equal(t0, t1) and np.array_equal(f0, f1)
