@@ -776,7 +776,12 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     __shared__ __align__(16) unsigned char s_union[4 * kPerlinRow * sizeof(double2)];
     static_assert(sizeof(s_union) >= kSigChunk * sizeof(SigRec), "signal chunk must fit");
     SigRec* s_sig = reinterpret_cast<SigRec*>(s_union);
-    __shared__ double s_w[256];                     // smear weights, widened once (the replay multiplies in f64)
+    // smear weights, widened once (the replay multiplies in f64), with 64 entries of padding on either side: the 64
+    // lanes of a tile that overlaps a signal's window then read 64 CONSECUTIVE doubles (bin - first lies in
+    // [-63, W + 62]), conflict-free, and the lanes outside the window are dropped by the select, not by a clamped
+    // address (the clamp sent them all to one address on a busy bank: 0.26 conflict cycles per LDS instruction)
+    constexpr int kWPad = 64;
+    __shared__ double s_w[256 + 2 * kWPad];
     __shared__ unsigned long long s_tiles[2];
     __shared__ float s_red[kColWaves];
     __shared__ unsigned char s_perm[256];
@@ -802,7 +807,10 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     const size_t base2 = (size_t)seg * 2 * P.cap;
 
     for (int i = tid; i < n_cells; i += kColThreads) lds_col[i] = 0.0f;
-    if (tid < W && P.signal_denoising > 0) s_w[tid] = (double)P.smear[tid];
+    for (int i = tid; i < 256 + 2 * kWPad; i += kColThreads) {
+        const int k = i - kWPad;
+        s_w[i] = (P.signal_denoising > 0 && k >= 0 && k < W) ? (double)P.smear[k] : 0.0;
+    }
     if (tid < 256) { s_perm[tid] = c_perm[tid]; s_grad[tid] = p_grad_coef(c_perm[tid]); }
     __syncthreads();
 
@@ -858,15 +866,15 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
             float acc = (g < n_cells) ? lds_col[g] : 0.0f;
             // scan 64 signals per step; replay the overlapping ones in order.  A lane outside 0 < g < C
             // gets a bin index that fails every range test (RadarCPU.cpp:424: bin 0 is never written)
-            const int gb8 = g_ok ? 8 * g : -0x40000000;      // byte offset of bin g in the f64 weight table
-            const unsigned W8 = 8u * (unsigned)W;
+            const int gb8 = 8 * g;                           // byte offset of bin g in the f64 weight table
+            const unsigned W8 = g_ok ? 8u * (unsigned)W : 0u;   // a lane outside 0 < g < C accepts no offset at all
             const char* wbytes = reinterpret_cast<const char*>(s_w);
             int2* list = s_list[wid];
             // one replay: acc = (float)((double)acc + (double)strength * w[g - first])   (RadarCPU.cpp:426)
 #define RR_REPLAY(E)                                                                                     \
             {                                                                                            \
                 const unsigned off = (unsigned)(gb8 - (E).x);                                            \
-                const double wv = *reinterpret_cast<const double*>(wbytes + min(off, W8 - 8u));          \
+                const double wv = *reinterpret_cast<const double*>(wbytes + 8 * kWPad + (int)off);       \
                 const float nv = (float)((double)acc + (double)__int_as_float((E).y) * wv);              \
                 acc = (off < W8) ? nv : acc;                                                             \
                 rmax = fmaxf(rmax, acc);       /* `if (slice > max_val) max_val = slice` (NaN never wins) */  \
