@@ -27,6 +27,8 @@
 namespace rr {
 namespace {
 
+float g_wz = 1.0f;   // set once per build (builds are not re-entrant across different weights)
+
 struct Box {
     float lo[3], hi[3];
     void reset() {
@@ -42,10 +44,12 @@ struct Box {
         for (int k = 0; k < 3; k++) { lo[k] = std::max(lo[k], b.lo[k]); hi[k] = std::min(hi[k], b.hi[k]); }
     }
     bool valid() const { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+    // "area" of the SAH = expected projection of the box for the ray distribution the tree is built for: isotropic
+    // rays see dx dy + dy dz + dz dx; g_wz < 1 discounts the horizontal face (see BvhOptions::vertical_weight)
     float half_area() const {
         float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
-        return dx * dy + dy * dz + dz * dx;
+        return g_wz * (dx * dy) + dy * dz + dz * dx;
     }
 };
 
@@ -121,7 +125,7 @@ struct Builder {
     std::atomic<int> tasks_left;          // threads that may still be started (subtree tasks and chunk workers)
     std::atomic<bool> failed{false};
     std::atomic<uint64_t> n_spatial{0}, n_refs_out{0};
-    float root_area = 0.f, alpha = 1e-5f;
+    float root_area = 0.f, alpha = 1e-5f, beta = 0.f;
     uint32_t max_leaf = kMaxLeafTris;
 
     struct ObjSplit { float cost; int axis, bin; Box lbox, rbox; };
@@ -315,7 +319,7 @@ struct Builder {
             bool try_spatial = os.axis < 0;
             if (os.axis >= 0) {
                 Box ov = os.lbox; ov.clip_to(os.rbox);
-                try_spatial = ov.valid() && ov.half_area() > alpha * root_area;
+                try_spatial = ov.valid() && ov.half_area() > alpha * root_area && ov.half_area() > beta * nb.half_area();
             }
             if (try_spatial) {
                 ss = best_spatial_split(refs, nb);
@@ -547,6 +551,9 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
     BvhOptions opt; if (opt_in) opt = *opt_in;
     if (const char* e = getenv("RR_BVH_ALPHA")) opt.sbvh_alpha = (float)atof(e);      // experiments (tools/treeq)
     if (const char* e = getenv("RR_BVH_BUDGET")) opt.ref_budget = (float)atof(e);
+    if (const char* e = getenv("RR_BVH_BETA")) opt.sbvh_beta = (float)atof(e);
+    if (const char* e = getenv("RR_BVH_WZ")) opt.vertical_weight = (float)atof(e);
+    g_wz = std::min(1.0f, std::max(0.01f, opt.vertical_weight));
     if (nf >= (1u << 28)) { err = "rr_set_mesh: more than 2^28 triangles"; return false; }
     if (nf && (!verts || !faces)) { err = "rr_set_mesh: null vertex/face pointer"; return false; }
     for (size_t i = 0; i < 3 * nf; i++) {
@@ -602,7 +609,7 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
         b.leaf_faces = leaf_faces.get(); b.leaf_cap = max_refs;
         b.budget = (int64_t)(max_refs - nf - 16 > 0 ? max_refs - nf - 16 : 0);
         b.tasks_left = n_threads - 1;
-        b.root_area = scene.half_area(); b.alpha = opt.sbvh_alpha;
+        b.root_area = scene.half_area(); b.alpha = opt.sbvh_alpha; b.beta = opt.sbvh_beta;
         b.max_leaf = kMaxLeafTris;
         Builder::Bounds bd; bd.reset();
         for (const Ref& r : refs) Builder::grow_bounds(bd, r);

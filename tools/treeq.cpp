@@ -137,6 +137,40 @@ int main(int argc, char** argv)
 #pragma omp parallel for schedule(dynamic, 256)
     for (long i = 0; i < (long)rays.size(); i++) cost[i] = trace(B, rays[i].o, rays[i].d, 1000.0f);
 
+    if (getenv("TREEQ_TWO_LEVEL")) {
+        // experiment: faces much larger than the median in their own tree, the rest in another; a ray walks the
+        // large-face tree first and the other one with the hit distance as its range
+        const size_t nf = faces.size() / 3;
+        std::vector<float> area(nf);
+        for (size_t f = 0; f < nf; f++) {
+            float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+            for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) { const float x = verts[3 * (size_t)faces[3 * f + v] + k]; lo[k] = std::min(lo[k], x); hi[k] = std::max(hi[k], x); }
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            area[f] = dx * dy + dy * dz + dz * dx;
+        }
+        std::vector<float> srt(area); std::nth_element(srt.begin(), srt.begin() + nf / 2, srt.end());
+        const float thr = srt[nf / 2] * (float)atof(getenv("TREEQ_TWO_LEVEL"));
+        std::vector<uint32_t> fl, fs;
+        for (size_t f = 0; f < nf; f++) { auto& dst = area[f] > thr ? fl : fs; for (int v = 0; v < 3; v++) dst.push_back(faces[3 * f + v]); }
+        Bvh4 BL, BS;
+        build_bvh4(verts.data(), verts.size() / 3, fl.data(), fl.size() / 3, nullptr, BL, err, threads);
+        build_bvh4(verts.data(), verts.size() / 3, fs.data(), fs.size() / 3, nullptr, BS, err, threads);
+        printf("two-level: %zu large faces (%zu nodes, %zu records), %zu small (%zu nodes, %zu records)\n", fl.size() / 3, BL.nodes.size(), BL.tris.size(), fs.size() / 3, BS.nodes.size(), BS.tris.size());
+        double n = 0, l = 0, t = 0;
+        std::vector<unsigned> st(rays.size());
+#pragma omp parallel for schedule(dynamic, 256) reduction(+:n,l,t)
+        for (long i = 0; i < (long)rays.size(); i++) {
+            const Cost a = fl.empty() ? Cost() : trace(BL, rays[i].o, rays[i].d, 1000.0f);
+            const float rm = a.t > 0 ? a.t * 1.0001f + 1e-3f : 1000.0f;
+            const Cost b = trace(BS, rays[i].o, rays[i].d, rm);
+            n += a.nodes + b.nodes; l += a.leaves + b.leaves; t += a.tris + b.tris; st[i] = a.nodes + a.leaves + b.nodes + b.leaves;
+        }
+        double ws = 0; size_t nw = 0;
+        for (size_t k = 0; k + 16 <= st.size(); k += 16) { unsigned mx = 0; for (size_t e = k; e < k + 16; e++) mx = std::max(mx, st[e]); ws += mx; nw++; }
+        const double m = (double)rays.size();
+        printf("two-level: nodes/ray %.2f leaves/ray %.2f tris/ray %.2f steps/ray %.2f wave iterations (est.) %.2f bytes/ray %.1f\n", n / m, l / m, t / m, (n + l) / m, ws / nw, (n * 128 + t * 48) / m + 132);
+    }
+
     size_t mism = 0;
     if (ref_face.size() == rays.size()) {
         for (size_t i = 0; i < rays.size(); i++) if (ref_face[i] != cost[i].face || ref_t[i] != cost[i].t) mism++;
