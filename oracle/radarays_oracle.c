@@ -140,6 +140,7 @@ typedef struct {
     double velocity;       /* :76 */
     double time;           /* :81 */
     uint32_t material_id;  /* :84 */
+    uint32_t dbg_parent;   /* tooling only (ORC_RAYLOG): index of the parent wave in the previous pass << 1 | 1 for a refraction */
 } wave_t;
 
 /* radar_types.h:108-113 -- Vector * double narrows the factor to float */
@@ -776,7 +777,8 @@ static int simulate_impl(const orc_scene* scene,
     int err = 0;
 
     /* tooling only (tools/treeq: BVH-quality study on real ray sets): ORC_RAYLOG=<file> appends every cast ray
-     * as { int32 azimuth, int32 pass, float o[3], float d[3] } in map coordinates */
+     * as { int32 azimuth, int32 pass, float o[3], float d[3], uint32 parent << 1 | refraction, uint32 material } in
+     * map coordinates (parent = index of the parent wave among the rays of the previous pass of that azimuth) */
     FILE* raylog = getenv("ORC_RAYLOG") ? fopen(getenv("ORC_RAYLOG"), "ab") : NULL;
 
     const double t_start = now_s();   /* RadarCPU.cpp:147-148 */
@@ -801,7 +803,7 @@ static int simulate_impl(const orc_scene* scene,
             wv.orig.x = 0.0f; wv.orig.y = 0.0f; wv.orig.z = 0.0f;
             wv.dir.x = beam_dirs[3 * i]; wv.dir.y = beam_dirs[3 * i + 1]; wv.dir.z = beam_dirs[3 * i + 2];
             wv.energy = 1.0; wv.polarization = 0.5; wv.velocity = 0.3; wv.time = 0.0;
-            wv.material_id = 0;
+            wv.material_id = 0; wv.dbg_parent = 0;
             wv_push(&waves, &wv);
         }
 
@@ -832,7 +834,8 @@ static int simulate_impl(const orc_scene* scene,
                     const int32_t hd[2] = { angle_id, pass_id };
                     const float od[6] = { o_m.x, o_m.y, o_m.z, d_m.x, d_m.y, d_m.z };
                     #pragma omp critical(raylog)
-                    { fwrite(hd, sizeof hd, 1, raylog); fwrite(od, sizeof od, 1, raylog); }
+                    { const uint32_t ex[2] = { wave.dbg_parent, wave.material_id };
+                      fwrite(hd, sizeof hd, 1, raylog); fwrite(od, sizeof od, 1, raylog); fwrite(ex, sizeof ex, 1, raylog); }
                 }
                 if (!scene_intersect(scene, o_m, d_m, &wave_range, &f, &st)) continue;   /* :252 */
                 tot_hits++;
@@ -872,6 +875,7 @@ static int simulate_impl(const orc_scene* scene,
                 if (fabs(reflection.energy - (double)thr) < 1e-6 || fabs(tenergy - (double)thr) < 1e-6) tot_near++;
                 if (reflection.energy > (double)thr)   /* :288 */
                 {
+                    reflection.dbg_parent = (uint32_t)i << 1;
                     wv_push(&waves_new, &reflection);
                     if ((int32_t)reflection.material_id == cfg->material_id_air)   /* :302 */
                     {
@@ -905,6 +909,7 @@ static int simulate_impl(const orc_scene* scene,
 
                 refraction.dir = tdir; refraction.energy = tenergy;   /* :364-365 */
                 if (refraction.energy > (double)thr) {
+                    refraction.dbg_parent = ((uint32_t)i << 1) | 1u;
                     wv_push(&waves_new, &refraction);
                 }
             }

@@ -33,7 +33,7 @@ static std::vector<T> slurp(const std::string& path)
     return v;
 }
 
-struct RayRec { int32_t az, pass; float o[3], d[3]; };
+struct RayRec { int32_t az, pass; float o[3], d[3]; uint32_t parent, mat; };
 struct Cost { unsigned nodes = 0, leaves = 0, tris = 0; float t = -1.f; uint32_t face = 0xFFFFFFFFu; unsigned nh[5] = {0,0,0,0,0}; unsigned leaves_after_hit = 0, nodes_after_hit = 0; };
 
 static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range_max)
@@ -209,6 +209,47 @@ int main(int argc, char** argv)
         printf("node visits by number of hit children 0..4 per ray: %.2f %.2f %.2f %.2f %.2f; after the first hit was found: %.2f nodes, %.2f leaves per ray\n",
                nh[0] / tr, nh[1] / tr, nh[2] / tr, nh[3] / tr, nh[4] / tr, nah / tr, lah / tr);
         printf("steps per ray percentiles: p10 %u p50 %u p90 %u p99 %u max %u\n", st[st.size() / 10], st[st.size() / 2], st[st.size() * 9 / 10], st[st.size() * 99 / 100], st.back());
+    }
+    if (getenv("TREEQ_PREDICT")) {
+        // which ordering of the later-pass rays of one azimuth gives waves of equal cost?  keys are things the GPU knows
+        // BEFORE it traces a ray: kind (reflection / refraction), material the ray travels in, cost of its parent
+        std::map<std::pair<int, int>, std::vector<size_t>> grp;       // (az, pass) -> ray indices in logged order
+        for (size_t i = 0; i < rays.size(); i++) grp[{ rays[i].az, rays[i].pass }].push_back(i);
+        auto waves = [&](const char* name, auto keyfn) {
+            double ws = 0; size_t nw = 0;
+            for (auto& kv : grp) {
+                if (kv.first.second == 0) continue;
+                std::vector<size_t> v = kv.second;
+                const auto& par = grp[{ kv.first.first, kv.first.second - 1 }];
+                std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) { return keyfn(a, par) < keyfn(b, par); });
+                for (size_t k = 0; k < v.size(); k += 16) {
+                    unsigned mx = 0;
+                    for (size_t e = k; e < std::min(v.size(), k + 16); e++) mx = std::max(mx, cost[v[e]].nodes + cost[v[e]].leaves);
+                    ws += mx; nw++;
+                }
+            }
+            printf("  order by %-44s wave iterations %.2f\n", name, ws / nw);
+        };
+        auto pcost = [&](size_t i, const std::vector<size_t>& par) -> double { const size_t p = par[rays[i].parent >> 1]; return cost[p].nodes + cost[p].leaves; };
+        waves("logged order (reference order)", [&](size_t, const std::vector<size_t>&) { return 0.0; });
+        waves("kind (reflections first)", [&](size_t i, const std::vector<size_t>&) { return (double)(rays[i].parent & 1); });
+        waves("material", [&](size_t i, const std::vector<size_t>&) { return (double)rays[i].mat; });
+        waves("material, kind", [&](size_t i, const std::vector<size_t>&) { return (double)rays[i].mat * 2 + (rays[i].parent & 1); });
+        waves("parent cost", [&](size_t i, const std::vector<size_t>& par) { return pcost(i, par); });
+        waves("material, kind, parent cost", [&](size_t i, const std::vector<size_t>& par) { return ((double)rays[i].mat * 2 + (rays[i].parent & 1)) * 1000 + pcost(i, par); });
+        waves("TRUE cost (bound)", [&](size_t i, const std::vector<size_t>&) { return (double)(cost[i].nodes + cost[i].leaves); });
+    }
+    if (getenv("TREEQ_SORTED")) {
+        // upper bound of what ANY re-ordering of the rays inside an (azimuth, pass) group could win: waves of 16 rays of
+        // equal cost (sorted by their true step count)
+        double ws = 0; size_t nw = 0;
+        std::map<std::pair<int, int>, std::vector<unsigned>> grp;
+        for (size_t i = 0; i < rays.size(); i++) grp[{ rays[i].pass, rays[i].az }].push_back(cost[i].nodes + cost[i].leaves);
+        for (auto& kv : grp) {
+            auto& v = kv.second; std::sort(v.begin(), v.end());
+            for (size_t k = 0; k < v.size(); k += 16) { ws += v[std::min(v.size(), k + 16) - 1]; nw++; }
+        }
+        printf("rays sorted by true cost inside each (azimuth, pass): wave iterations %.2f\n", ws / nw);
     }
     printf("all   : %8zu rays  nodes/ray %6.2f  leaves/ray %5.2f  tris/ray %6.2f  steps/ray %6.2f  wave iterations (est.) %6.2f  bytes/ray %7.1f\n",
            tr, tn / tr, tl / tr, tt / tr, (tn + tl) / tr, tw / twv, (tn * 128 + tt * 48) / tr + 132);

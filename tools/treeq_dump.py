@@ -25,4 +25,4 @@ m = [x.astuple() for x in materials_for(s)]
 pose = scenes.trajectory(16, s["name"])[3]
 for a in np.linspace(0, 400, n_az, endpoint=False).astype(int):
     O.simulate(sc, m, s["object_materials"], cfg, golden_beams(n_rays), pose, az_begin=int(a), az_end=int(a) + 1, n_threads=1)
-print("rays:", os.path.getsize(log) // 32)
+print("rays:", os.path.getsize(log) // 40)
