@@ -293,8 +293,16 @@ def main():
         if os.path.exists(cf):
             counters = json.load(open(cf)).get(args.workload, {})
         kc = counters.get("kernels", {}).get(dominant, {})
+        n_launch_frames = fpb // world                      # frames one launch of this rank covers
+        # the counters were collected with `frames_per_launch` frames per launch (the default batch shape); another
+        # shape (--strong, --frames-per-rank) does proportionally more or less work per launch
+        scale = n_launch_frames / float(counters.get("frames_per_launch", n_launch_frames) or n_launch_frames)
         insts = kc.get("SQ_INSTS_VALU")                     # wave-instructions per launch (PMC, same command)
         traffic = kc.get("hbm_bytes")
+        if insts is not None:
+            insts = int(round(insts * scale))
+        if traffic is not None:
+            traffic = int(round(traffic * scale))
         iso_ms, iso_n = iso[dominant]
         iso_s = 1e-3 * iso_ms / max(iso_n, 1)
         if dominant in live and live[dominant][1] > 0:
@@ -302,7 +310,6 @@ def main():
             live_n = int(live[dominant][1])
         else:                                               # a kernel other than k_trace dominates: isolated figure only
             live_s, live_n = iso_s, int(iso_n)
-        n_launch_frames = fpb // world                      # frames one launch of this rank covers
         wp_launch = wave_passes_batch_rank / max(n_pass, 1)  # mean wave-passes of one k_trace launch
         achieved = (insts / live_s) if (insts and live_s > 0) else None
         roof = {"bound": "valu_issue", "kernel": KERNEL_LABEL[dominant],

@@ -57,6 +57,13 @@ for wl, suffix in pairs:
             if c in m:
                 e[c] = int(round(m[c]))
         kernels[k] = e
-    out[wl] = {"source": "profiles/%s%s_pmc_summary.json" % (tag, suffix), "kernels": kernels}
+    fpl = 8
+    bf = os.path.join(here, "%s%s_bench_under_rocprof.json" % (tag, suffix))
+    if os.path.exists(bf):
+        try:
+            b = json.load(open(bf)); fpl = int(b["config"]["frames_per_batch"]) // max(int(b["n_gpus"]), 1)
+        except Exception:
+            pass
+    out[wl] = {"source": "profiles/%s%s_pmc_summary.json" % (tag, suffix), "frames_per_launch": fpl, "kernels": kernels}
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {kk: vv.get("SQ_INSTS_VALU") for kk, vv in v["kernels"].items()} for k, v in out.items() if k != "_how"}, indent=1))
