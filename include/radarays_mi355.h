@@ -276,6 +276,11 @@ int rr_multi_device_count(const rr_multi* m);
 rr_ctx* rr_multi_ctx(rr_multi* m, int i);                        /* the context of device i (stats, tuning) */
 /* azimuth block [*begin, *end) of `rank` among `world`: contiguous, sizes differ by at most one column */
 void rr_partition(int n_angles, int world, int rank, int* begin, int* end);
+/* the data plan of one rr_multi_simulate_batch call (pure arithmetic, no GPU): whether the blocks are equal (all-gather
+ * of bytes_per_device per device) and, for the ragged case, for device r and frame f (index r * n_frames + f) the byte
+ * offset of the piece in r's block buffer, its offset in the root's [n_frames][n_angles][n_cells] buffer and its size */
+int rr_multi_plan(int n_angles, int n_cells, int n_devices, int n_frames, int* equal_blocks, size_t* bytes_per_device,
+                  size_t* send_off, size_t* recv_off, size_t* piece_bytes);
 /* replicated setters: same contracts as the rr_set_* calls above, applied to every device */
 int rr_multi_set_mesh(rr_multi* m, const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object_id);
 int rr_multi_set_materials(rr_multi* m, const rr_material* materials, size_t n_materials,

@@ -188,6 +188,32 @@ int rr_multi_set_motion_poses(rr_multi* m, const float* poses, size_t n)
     return 0;
 }
 
+// ---- the data plan of one call: pure arithmetic, exported so that it can be checked without a GPU ------------
+// equal blocks : every device all-gathers `bytes_per_device`; device r's block lands at r * bytes_per_device of the
+//                gathered buffer, laid out [device][frame][n_loc][n_cells]
+// ragged blocks: device r sends, for every frame f, the n_loc_r * n_cells bytes at send_off[r][f] of ITS block buffer
+//                ([frame][n_loc_r][n_cells]) to the root, which receives them at recv_off[r][f] of [frame][n_angles][n_cells]
+int rr_multi_plan(int n_angles, int n_cells, int n_devices, int n_frames, int* equal_blocks, size_t* bytes_per_device,
+                  size_t* send_off, size_t* recv_off, size_t* piece_bytes)
+{
+    if (n_angles < 1 || n_cells < 1 || n_devices < 1 || n_frames < 1) return -3;
+    bool equal = true; int b0 = 0, e0 = 0;
+    rr_partition(n_angles, n_devices, 0, &b0, &e0);
+    for (int r = 0; r < n_devices; r++) {
+        int b = 0, e = 0; rr_partition(n_angles, n_devices, r, &b, &e);
+        equal = equal && (e - b) == (e0 - b0);
+        for (int f = 0; f < n_frames; f++) {
+            const size_t k = (size_t)r * n_frames + f;
+            if (send_off) send_off[k] = (size_t)f * (size_t)(e - b) * n_cells;
+            if (recv_off) recv_off[k] = ((size_t)f * n_angles + (size_t)b) * n_cells;
+            if (piece_bytes) piece_bytes[k] = (size_t)(e - b) * n_cells;
+        }
+    }
+    if (equal_blocks) *equal_blocks = equal ? 1 : 0;
+    if (bytes_per_device) *bytes_per_device = (size_t)n_frames * (size_t)(e0 - b0) * n_cells;
+    return 0;
+}
+
 // ---- frames ------------------------------------------------------------------------------------------------
 int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8_t* out_imgs_u8)
 {
@@ -226,14 +252,16 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
     } else {
         RRM_HIP(m, hipSetDevice(m->devices[0]));
         RRM_HIP(m, m->gathered[0].ensure((size_t)n_frames * A * C));
+        std::vector<size_t> so((size_t)n * n_frames), ro((size_t)n * n_frames), pb((size_t)n * n_frames);
+        (void)rr_multi_plan(A, (int)C, n, n_frames, nullptr, nullptr, so.data(), ro.data(), pb.data());
         RRM_NCCL(m, g_rccl.GroupStart());
-        for (int i = 0; i < n; i++) {
-            const size_t nl = (size_t)(e[(size_t)i] - b[(size_t)i]);
-            for (int f = 0; f < n_frames && nl; f++) {
-                RRM_NCCL(m, g_rccl.Send(m->block[(size_t)i].p + (size_t)f * nl * C, nl * C, kNcclUint8, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
-                RRM_NCCL(m, g_rccl.Recv(m->gathered[0].p + ((size_t)f * A + (size_t)b[(size_t)i]) * C, nl * C, kNcclUint8, i, m->comms[0], m->streams[0]));
+        for (int i = 0; i < n; i++)
+            for (int f = 0; f < n_frames; f++) {
+                const size_t k = (size_t)i * n_frames + f;
+                if (pb[k] == 0) continue;
+                RRM_NCCL(m, g_rccl.Send(m->block[(size_t)i].p + so[k], pb[k], kNcclUint8, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
+                RRM_NCCL(m, g_rccl.Recv(m->gathered[0].p + ro[k], pb[k], kNcclUint8, i, m->comms[0], m->streams[0]));
             }
-        }
         RRM_NCCL(m, g_rccl.GroupEnd());
         d_cols = m->gathered[0].p;                         // [n_frames][A][C]
     }

@@ -21,7 +21,7 @@ SYMBOLS = [
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_set_timing_mode",
     "rr_get_kernel_time", "rr_get_kernel_samples", "rr_reserve_timing_events",
-    "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_partition",
+    "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_partition", "rr_multi_plan",
     "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_ctx",
     "rr_multi_set_mesh", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
     "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
@@ -132,6 +132,7 @@ def lib():
     L.rr_host_free.restype = None
     L.rr_partition.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rr_partition.restype = None
+    L.rr_multi_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), vp, vp, vp]
     L.rr_create_multi.restype = vp
     L.rr_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.rr_destroy_multi.argtypes = [vp]
@@ -403,6 +404,17 @@ def partition(n_angles, world, rank):
     b, e = C.c_int(), C.c_int()
     lib().rr_partition(int(n_angles), int(world), int(rank), C.byref(b), C.byref(e))
     return b.value, e.value
+
+
+def multi_plan(n_angles, n_cells, n_devices, n_frames):
+    """rr_multi_plan -> (equal, bytes_per_device, send_off[r][f], recv_off[r][f], piece_bytes[r][f])"""
+    eq, bpd = C.c_int(), C.c_size_t()
+    so = np.zeros((n_devices, n_frames), np.uint64); ro = np.zeros_like(so); pb = np.zeros_like(so)
+    assert C.sizeof(C.c_size_t) == 8
+    rc = lib().rr_multi_plan(n_angles, n_cells, n_devices, n_frames, C.byref(eq), C.byref(bpd), so.ctypes.data, ro.ctypes.data, pb.ctypes.data)
+    if rc:
+        raise RRError("rr_multi_plan: rc=%d" % rc)
+    return bool(eq.value), int(bpd.value), so, ro, pb
 
 
 class MultiContext:

@@ -112,3 +112,45 @@ def test_multi_create_refuses_bad_device_lists(native_lib):
     d = (C.c_int * 2)(0, 0)
     assert not L.rr_create_multi(d, 2)
     assert b"twice" in L.rr_multi_last_error(None)
+
+
+def test_multi_plan_covers_every_frame_exactly_once(native_lib):
+    """rr_multi_plan = the send / receive plan of rr_multi_simulate_batch (csrc/rr_multi.hip), pure arithmetic.  Emulated
+    here with numpy: every device's block buffer [frame][n_loc_r][n_cells] is filled with (device, frame, column, cell)
+    tags, the plan is applied, and the root's [frame][n_angles][n_cells] buffer must hold azimuth a of frame f where the
+    assemble kernel reads it -- for ragged blocks (send/recv pieces) and for equal blocks (all-gather layout
+    [device][frame][n_loc][n_cells] addressed with block_stride / frame_stride as rr_assemble_frames_device does)."""
+    import numpy as np
+    for n_angles, n_dev, n_frames, C_ in ((400, 8, 3, 5), (400, 7, 2, 4), (10, 4, 3, 2), (5, 8, 1, 3), (400, 1, 4, 2), (401, 3, 2, 2)):
+        eq, bpd, so, ro, pb = native_lib.multi_plan(n_angles, C_, n_dev, n_frames)
+        blocks = [native_lib.partition(n_angles, n_dev, r) for r in range(n_dev)]
+        assert eq == (len({e - b for b, e in blocks}) == 1)
+        bufs = []
+        for r, (b, e) in enumerate(blocks):        # tag = frame * 1e6 + azimuth * 1e2 + cell
+            blk = np.zeros((n_frames, e - b, C_), np.int64)
+            for f in range(n_frames):
+                for a in range(b, e):
+                    blk[f, a - b] = f * 1_000_000 + a * 100 + np.arange(C_)
+            bufs.append(blk.ravel())
+        want = np.zeros((n_frames, n_angles, C_), np.int64)
+        for f in range(n_frames):
+            for a in range(n_angles):
+                want[f, a] = f * 1_000_000 + a * 100 + np.arange(C_)
+        # ragged plan (valid for equal blocks too): pieces
+        root = np.full(n_frames * n_angles * C_, -1, np.int64)
+        for r in range(n_dev):
+            for f in range(n_frames):
+                n = int(pb[r, f])
+                root[int(ro[r, f]):int(ro[r, f]) + n] = bufs[r][int(so[r, f]):int(so[r, f]) + n]
+        assert np.array_equal(root.reshape(want.shape), want)
+        if eq:                                      # all-gather layout + the assemble kernel's block addressing
+            n_loc = blocks[0][1] - blocks[0][0]
+            assert bpd == n_frames * n_loc * C_
+            gathered = np.concatenate(bufs)         # [device][frame][n_loc][cells]
+            block_stride, frame_stride = bpd, n_loc * C_
+            got = np.zeros_like(want)
+            for f in range(n_frames):
+                for a in range(n_angles):
+                    off = (a // n_loc) * block_stride + f * frame_stride + (a % n_loc) * C_
+                    got[f, a] = gathered[off:off + C_]
+            assert np.array_equal(got, want)
