@@ -156,9 +156,22 @@ def main():
             shard.step([poses[((k * bps + b) * fpb + f) % len(poses)] for f in range(fpb)], None,
                        done_event=done if b == bps - 1 else None)
 
-    def prewarm(fn, seconds=PREWARM_S):
-        """untimed: at least `seconds` of steps so the timed region starts at sustained clocks"""
+    def prewarm(fn, seconds=PREWARM_S, collective=False):
+        """untimed: at least `seconds` of steps so the timed region starts at sustained clocks.  With a collective
+        inside the step every rank must run the SAME number of steps: the count is derived from the slowest rank's
+        time for the first four."""
         t0, k = time.perf_counter(), 0
+        if collective and world > 1:
+            for k in range(4):
+                fn(k)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            more = int(math.ceil(seconds / max(float(t.item()) / 4.0, 1e-6))) - 4
+            for k in range(4, 4 + max(more, 0)):
+                fn(k)
+            torch.cuda.synchronize()
+            return 4 + max(more, 0)
         while True:
             fn(k); k += 1
             if k % 4 == 0:
@@ -184,7 +197,7 @@ def main():
     ctx.set_stats_mode(False)
     # every kernel alone on the GPU (one batch at a time, nothing else in flight): which kernel takes the most
     # time, and its own speed -- as opposed to its duration while several batches share the chip below
-    prewarm(step)
+    prewarm(step, collective=True)
     ctx.reserve_timing_events(4096)
     ctx.set_timing_mode(1)
     for name in KERNEL_LABEL:
@@ -199,7 +212,7 @@ def main():
     # (timing mode 2: pooled hipExtLaunchKernel events around the k_trace launches only, on the launch stream)
     done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     ctx.reserve_timing_events(2 * n_pass * bps * args.steps + 64)
-    prewarm(step)
+    prewarm(step, collective=True)
     ctx.set_timing_mode(2)
     ctx.kernel_time("trace", reset=True); ctx.kernel_time("trace0", reset=True)
     if world > 1:
