@@ -102,8 +102,10 @@ int     rr_abi_version(void);
 
 /* Replaces rm::import_embree_map (src/radar_simulator.cpp:149): triangle soup
  * + per-face object id (index into object_materials; NULL -> all 0).  Builds
- * the BVH on the host and uploads it.  Inputs are copied.  Size limit: 8 x BVH4 nodes + 3 x triangles
- * < 2^28 (child references are 28-bit offsets), i.e. about 60M triangles. */
+ * the BVH on the host (SAH over references with spatial splits: a face larger than its neighbours may be cut and
+ * then has one triangle record per leaf that holds a part of it) and uploads it.  Inputs are copied.  Size limit:
+ * 8 x BVH4 nodes + 3 x triangle records < 2^28 (child references are 28-bit offsets), i.e. about 50M triangles; a
+ * mesh whose split parts would exceed it is built without spatial splits. */
 int rr_set_mesh(rr_ctx* ctx, const float* verts /*[nv][3]*/, size_t nv,
                 const uint32_t* faces /*[nf][3]*/, size_t nf,
                 const uint32_t* face_object_id /*[nf] or NULL*/);

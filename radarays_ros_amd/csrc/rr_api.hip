@@ -641,6 +641,11 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     RR_HIP(c, hipSetDevice(c->device));
     Bvh4 bvh; std::string err;
     if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err)) return fail(c, -4, err);
+    if (bvh.spatial_splits > 0 && bvh.nodes.size() * 8 + (bvh.tris.size() + 4) * 3 >= (1ull << 28)) {
+        // the parts spatial splits add pushed the tree over the 28-bit reference range: build without them
+        BvhOptions plain; plain.sbvh_alpha = -1.0f;
+        if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err, 0, &plain)) return fail(c, -4, err);
+    }
     // frames in flight on the lane streams or a caller's stream (all non-blocking: a blocking hipMemcpy
     // does not order against them) still trace the old tree
     RR_HIP(c, hipDeviceSynchronize());
