@@ -325,6 +325,16 @@ def main():
             live_s, live_n = iso_s, int(iso_n)
         wp_launch = wave_passes_batch_rank / max(n_pass, 1)  # mean wave-passes of one k_trace launch
         achieved = (insts / live_s) if (insts and live_s > 0) else None
+        chip = None
+        ks = counters.get("kernels", {})
+        if ks and all(k in ks for k in ("trace0", "column", "shade")):
+            per_batch = {"trace0": 1, "trace": max(n_pass - 1, 0), "shade": n_pass, "scan": max(n_pass - 1, 0), "column": 1, "assemble": 1}
+            tot = sum(ks[k]["SQ_INSTS_VALU"] * n * scale for k, n in per_batch.items() if k in ks and n)
+            t_batch = elapsed / (args.steps * bps)
+            chip = {"wave_instr_per_batch": int(tot), "achieved": round(tot / t_batch / 1e9, 2),
+                    "frac": round(tot / t_batch / VALU_PEAK_WAVE_INSTR_S, 4),
+                    "what": "all kernels of a batch (SQ_INSTS_VALU per launch x launches per batch) / measured time per batch; "
+                            "the dominant kernel's own `frac` is lower because %d batches share the chip" % args.slots}
         roof = {"bound": "valu_issue", "kernel": KERNEL_LABEL[dominant],
                 "achieved": None if achieved is None else round(achieved / 1e9, 2),
                 "peak": round(VALU_PEAK_WAVE_INSTR_S / 1e9, 1), "unit": "G wave-instr/s",
@@ -340,6 +350,9 @@ def main():
                              "achieved": None if not insts or iso_s <= 0 else round(insts / iso_s / 1e9, 2),
                              "frac": None if not insts or iso_s <= 0 else round(insts / iso_s / VALU_PEAK_WAVE_INSTR_S, 4),
                              "what": "the same launches with ONE batch on the GPU at a time"},
+                # the chip as a whole in the timed region: every kernel's instructions (PMC per launch x launches per
+                # batch) over the measured time per batch
+                "chip": chip,
                 "kernel_time_share_isolated": {KERNEL_LABEL[n]: round(iso[n][0] / max(sum(v[0] for v in iso.values()), 1e-9), 4) for n in iso},
                 # secondary views (never `frac`): what crosses the HBM interface, and the SURVEY §8d algorithmic byte rate
                 "hbm_measured": (None if not traffic or live_s <= 0 else
