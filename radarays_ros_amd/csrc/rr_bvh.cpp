@@ -11,6 +11,9 @@
 // reference is cut in two (its triangle is clipped against the plane for tight boxes), unless keeping it whole on
 // one side is cheaper ("reference unsplitting").  A face may therefore sit in several leaves; the nearest hit is
 // the minimum over (t, face id), so duplicates cannot change a result (rr_kernels.hip, traverse()).
+// The "area" of every SAH decision carries a vertical weight (BvhOptions::vertical_weight, rr_bvh.h): radar rays
+// are mostly horizontal.  Parallelism: subtrees are tasks; inside a big node binning and partitioning run over
+// fixed-size chunks of the reference list (merged in chunk order, so the tree does not depend on the thread count).
 #include "rr_bvh.h"
 
 #include <algorithm>
