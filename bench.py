@@ -18,7 +18,7 @@ region; poses are 7 floats passed as kernel arguments.  Timing bracket = the ref
 `value`: images left in HBM ("inputs resident, output resident": the bench contract).  Because the reference's
 simulate() ends with the image in HOST memory (m_polar_image, RadarCPU.cpp:542,555-561), the same line carries
 `host_resident`: the same K steps timed THROUGH the last D2H copy of every image into page-locked host memory
-(rr_simulate_batch_host_async: copy ordered behind the batch on its stream, overlapped with the batches on the other streams), and `single_pose`: one pose per
+(rr_simulate_batch_host_async: the images ride out on the trace launches of the lane's next batch, a few waves with one store in flight each), and `single_pose`: one pose per
 launch set (the latency-oriented shape a live ROS node would use).  Before every timed region the GPU is
 pre-warmed by wall time (>= 0.3 s of steps, untimed) so that `--steps 20` reads sustained clocks.
 
@@ -275,8 +275,8 @@ def main():
         th1 = time.perf_counter()
         host_res = {"value": round(args.steps * bps * F / (th1 - th0), 2), "unit": "images/s",
                     "ms_per_step": round(1e3 * (th1 - th0) / args.steps, 4),
-                    "what": "same steps, every mono8 image copied to page-locked host memory behind its batch "
-                            "(rr_simulate_batch_host_async), timed through the last copy",
+                    "what": "same steps, every mono8 image delivered to page-locked host memory (rr_simulate_batch_host_async: "
+                            "trickled out by a few waves of the next batch's trace launches), timed through the last copy",
                     "d2h_GBps": round(args.steps * bps * F * npx / (th1 - th0) / 1e9, 3)}
         for h in hosts:
             h.close()

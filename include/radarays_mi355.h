@@ -181,11 +181,15 @@ int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint
 
 /* The reference leaves every frame in HOST memory (m_polar_image -> sensor_msgs::Image, RadarCPU.cpp:542,555-561).
  * Whole frames of n_frames poses like rr_simulate_batch_device, delivered to the caller's host buffer
- * h_imgs_u8 = [n_frames][n_cells][n_angles]: kernels, then ONE D2H copy, all ordered on `stream`; batches in flight
- * on the caller's other streams keep the GPU busy meanwhile (four streams in total is the measured optimum: HIP
- * maps streams onto four hardware queues).  Returns at once; the images are complete after
- * rr_wait_host(ctx, h_imgs_u8) (NULL: every outstanding copy) or rr_synchronize().  For a copy that really
- * overlaps, h_imgs_u8 must be page-locked: rr_host_alloc / rr_host_free (hipHostMalloc). */
+ * h_imgs_u8 = [n_frames][n_cells][n_angles].  Returns at once; the images are COMPLETE ONLY after rr_wait_host(ctx,
+ * h_imgs_u8) (NULL: every outstanding buffer) or rr_synchronize() -- until then the buffer must stay valid and must not be
+ * read.  How the bytes travel is the library's business: a batch's images wait in device memory and ride out on the
+ * trace launches of the next batch that uses the same frame lane (a few waves trickle them over PCIe with one store in
+ * flight each, which keeps the stores of the running kernels from queueing behind them: within 1 % of the rate with the
+ * images left in HBM, where a plain copy behind each batch costs 7 %); rr_wait_host / rr_synchronize / any other use of
+ * the lane send what is still waiting with a plain copy.  Issue batches on up to four streams (HIP maps streams onto
+ * four hardware queues) and hand the buffers out from a ring twice as deep as the batches in flight.  h_imgs_u8
+ * should be page-locked (rr_host_alloc / rr_host_free = hipHostMalloc); a pageable buffer works through the plain copy. */
 int rr_simulate_batch_host_async(rr_ctx* ctx, const float* poses, int n_frames, uint8_t* h_imgs_u8, void* stream);
 int rr_wait_host(rr_ctx* ctx, const void* h_imgs_u8);
 void* rr_host_alloc(size_t bytes);

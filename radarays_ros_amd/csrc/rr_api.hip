@@ -86,6 +86,11 @@ struct Lane {
     hipEvent_t ev_copied = nullptr;
     bool pending_copy = false;
     const void* copy_dst = nullptr;
+    // a batch's images stay in d_img_u8 ("deferred") until the lane's NEXT host-delivery batch, whose later-pass trace
+    // launches carry the copy (see Params::copy_src); rr_wait_host / rr_synchronize / any other use of the lane flush a
+    // deferred copy with a plain hipMemcpyAsync
+    bool deferred = false;
+    uint8_t* def_dst = nullptr; size_t def_bytes = 0; hipStream_t def_stream = nullptr; bool def_foldable = false;
 };
 
 struct rr_ctx {
@@ -147,6 +152,8 @@ struct rr_ctx {
     }
 
     bool roctx = false;
+    int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
+    int copy_blocks = 4;         // workgroups (2 waves each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
 };
 
 namespace {
@@ -452,6 +459,18 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.pass0_az = c->pass0_az;
 }
 
+// the lane's deferred host copy, now, as a plain copy on the stream its batch ran on
+int flush_deferred(rr_ctx* c, Lane& L)
+{
+    if (!L.deferred) return 0;
+    RR_HIP(c, hipMemcpyAsync(L.def_dst, L.d_img_u8.p, L.def_bytes, hipMemcpyDeviceToHost, L.def_stream));
+    RR_HIP(c, hipEventRecord(L.ev_copied, L.def_stream));
+    RR_HIP(c, hipEventRecord(L.ev_consumed, L.def_stream));
+    L.pending_consume = true; L.pending_copy = true; L.copy_dst = L.def_dst;
+    L.deferred = false;
+    return 0;
+}
+
 struct TimedScope {
     rr_ctx* c; hipStream_t s; const char* name; hipEvent_t a = nullptr, b = nullptr;
     bool on;
@@ -486,7 +505,8 @@ int check_ready(rr_ctx* c)
 
 int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
               uint8_t* d_cols_u8 /* null: the lane's own buffer */, float* d_cols_f32, hipStream_t s, int n_frames = 1,
-              const float4* d_matsets = nullptr, int mat_stride = 0, bool lane_f32 = false)
+              const float4* d_matsets = nullptr, int mat_stride = 0, bool lane_f32 = false,
+              const uint8_t* copy_src = nullptr, uint8_t* copy_dst = nullptr, size_t copy_bytes = 0)
 {
     const rr_config& g = c->cfg;
     if (az_begin < 0 || az_end > g.n_angles || az_begin > az_end) return fail(c, -3, "azimuth range out of bounds");
@@ -513,6 +533,14 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
     L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
     for (int pass = 0; pass < g.n_reflections; pass++) {
+        // the previous batch's images ride on the later-pass launches, one slice each (rr_simulate_batch_host_async)
+        P.copy_blocks = 0;
+        if (pass >= 1 && copy_src) {
+            const size_t n16 = copy_bytes / 16, slices = (size_t)g.n_reflections - 1, k = (size_t)pass - 1;
+            const size_t b = n16 * k / slices, e = n16 * (k + 1) / slices;
+            P.copy_src = reinterpret_cast<const uint4*>(copy_src) + b; P.copy_dst = reinterpret_cast<uint4*>(copy_dst) + b;
+            P.copy_n16 = e - b; P.copy_blocks = c->copy_blocks;
+        }
         if (c->roctx) roctx_push(pass == 0 ? "trace pass 0" : "trace");
         if (c->timing) {
             // the kernel's own begin/end timestamps (hipExtLaunchKernel events), on its launch stream
@@ -596,6 +624,8 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_PASS0_AZ")) { const int a = atoi(getenv("RR_PASS0_AZ")); if (a == 1 || a == 2 || a == 4 || a == 8 || a == 16) c->pass0_az = a; }
     if (getenv("RR_STACK_LDS")) c->stack_lds_max = std::max(1, std::min(64, atoi(getenv("RR_STACK_LDS"))));
     if (getenv("RR_ROCTX") && atoi(getenv("RR_ROCTX")) != 0) c->roctx = roctx_load();
+    if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
+    if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(13, atoi(getenv("RR_COPY_BLOCKS"))));
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -805,6 +835,7 @@ int rr_simulate_columns_device(rr_ctx* c, const float pose[7], int az_begin, int
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const size_t li = c->next_lane++ % c->lanes.size();
     Lane& L = c->lanes[li];
+    { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     rc = run_frame(c, L, pose, az_begin, az_end, d_cols_u8, d_cols_f32, s); if (rc) return rc;
@@ -822,6 +853,7 @@ int rr_simulate_batch_columns_device(rr_ctx* c, const float* poses, int n_frames
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const size_t li = c->next_lane++ % c->lanes.size();
     Lane& L = c->lanes[li];
+    { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     rc = run_frame(c, L, poses, az_begin, az_end, d_cols_u8, nullptr, s, n_frames); if (rc) return rc;
@@ -841,6 +873,7 @@ int rr_simulate_batch_device(rr_ctx* c, const float* poses, int n_frames, uint8_
     rc = upload_tables(c); if (rc) return rc;
     const size_t li = c->next_lane++ % c->lanes.size();
     Lane& L = c->lanes[li];
+    { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames); if (rc) return rc;
@@ -875,32 +908,52 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     Lane& L = c->lanes[li];
     c->last_lane = li;
     const size_t bytes = (size_t)n_frames * g.n_cells * g.n_angles;
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));   // the lane's previous batch, incl. its assemble
+    // the images the lane's previous batch left behind ride on this batch's later-pass launches when possible
+    // ... and worthwhile: the trickle (one 1-KB store per wave in flight, a few waves) needs about 1 ms per launch for 8
+    // images, which hides behind a launch only while other batches share the GPU with it; a caller with a single batch
+    // in flight gets the plain copy
+    int busy = 0;
+    for (Lane& M : c->lanes) if (&M != &L && M.pending_consume && hipEventQuery(M.ev_consumed) == hipErrorNotReady) busy++;
+    (void)hipGetLastError();
+    const bool fold = L.deferred && L.def_foldable && c->copy_blocks > 0 && g.n_reflections >= 2 && L.def_bytes % 16 == 0 &&
+                      L.d_img_u8.n >= bytes && !c->stats_mode && busy >= c->fold_min_busy;
+    const uint8_t* job_src = nullptr; uint8_t* job_dst = nullptr; size_t job_bytes = 0;
+    if (fold) { job_src = L.d_img_u8.p; job_dst = L.def_dst; job_bytes = L.def_bytes; L.deferred = false; }
+    else { rc = flush_deferred(c, L); if (rc) return rc; if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0)); }
     if (L.d_img_u8.n < bytes) {
         RR_HIP(c, hipDeviceSynchronize());      // an earlier copy may still read the old buffer
         RR_HIP(c, L.d_img_u8.ensure(bytes));
     }
-    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));   // incl. the lane's last D2H copy
-    rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames); if (rc) return rc;
+    rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames, nullptr, 0, false, job_src, job_dst, job_bytes);
+    if (rc) {
+        if (fold) {     // the frame was refused before any launch: the folded copy still has to happen
+            RR_HIP(c, hipMemcpyAsync(job_dst, job_src, job_bytes, hipMemcpyDeviceToHost, s));
+            RR_HIP(c, hipEventRecord(L.ev_copied, s)); L.pending_copy = true; L.copy_dst = job_dst;
+        }
+        return rc;
+    }
+    if (fold) { RR_HIP(c, hipEventRecord(L.ev_copied, s)); L.pending_copy = true; L.copy_dst = job_dst; }   // behind the launches that carried it
     { TimedScope t(c, s, "assemble");
       launch_assemble_u8(L.d_cols_u8.p, L.d_img_u8.p, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
                          (size_t)g.n_angles * g.n_cells, n_frames, (size_t)g.n_angles * g.n_cells); }
     RR_HIP(c, hipGetLastError());
-    // The D2H is ordered on the SAME stream behind the assemble (a blit kernel: 0.2 ms per 8 images alone, 0.27-0.39 ms
-    // beside the other batches).  Measured on the 10M-triangle target (tools/probe_hostpath.py, 8 poses per batch,
-    // 4 streams; 3,950-3,975 images/s with the images left in HBM): this form 3,670-3,775; a separate copy stream
-    // beside 4 batch streams 3,250-3,590 (HIP maps streams onto 4 hardware queues: the fifth shares one with a batch
-    // stream and its event waits stall that batch), beside 3 batch streams 3,700-3,840; the assemble kernel writing
-    // straight into the host buffer 3,515; an own copy kernel of 4..128 workgroups 3,590-3,650; the copy folded into
-    // the next batch's pass-1 trace launch (8..400 extra grid rows, no dispatch of its own) 3,580-3,650.  Whatever
-    // issues the stores, the frame rate drops by about the PCIe transfer time of the images (11 MB at 54 GB/s =
-    // 0.2 ms per 2 ms batch): on this platform device -> host traffic does not overlap the kernels.
-    if (c->roctx) roctx_push("image D2H");
-    RR_HIP(c, hipMemcpyAsync(h_imgs_u8, L.d_img_u8.p, bytes, hipMemcpyDeviceToHost, s));
-    if (c->roctx) roctx_pop();
-    RR_HIP(c, hipEventRecord(L.ev_copied, s));
     RR_HIP(c, hipEventRecord(L.ev_consumed, s));
     L.pending_consume = true;
-    L.pending_copy = true; L.copy_dst = h_imgs_u8;
+    // Where do the images go from here?  A copy issued behind the batch costs the frame rate about the PCIe transfer
+    // time of the images, whoever stores the bytes (tools/probe_hostpath.py, 10M-triangle target, 8 poses per batch, 4
+    // streams; 3,950-4,050 images/s with the images left in HBM): hipMemcpyAsync on this stream 3,670-3,775; a separate
+    // copy stream 3,250-3,840 (a fifth stream shares a hardware queue with a batch stream); the assemble kernel writing
+    // straight into the host buffer 3,515; an own copy kernel of 4..128 workgroups 3,590-3,650; the copy folded into a
+    // trace launch with all its stores in flight 3,580-3,650 -- while copies of 1 MB per batch cost nothing
+    // (tools/probe_fence.py).  What stalls is the memory pipeline: stores to host memory drain at PCIe speed, and once
+    // they fill its write queues the stores of every other kernel wait behind them.  So the copy is DEFERRED to the lane's
+    // next batch and trickled out by a few waves of its later-pass trace launches with ONE store per wave in flight
+    // (k_trace, Params::copy_src): 3,980-4,025 images/s, within 1 % of the HBM-resident rate.
+    hipPointerAttribute_t at;
+    const bool device_visible = hipPointerGetAttributes(&at, h_imgs_u8) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();     // a pageable pointer makes hipPointerGetAttributes fail: not an error of this call
+    L.deferred = true; L.def_dst = h_imgs_u8; L.def_bytes = bytes; L.def_stream = s; L.def_foldable = device_visible;
     return 0;
 }
 
@@ -908,11 +961,13 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
 {
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
-    for (Lane& L : c->lanes)
+    for (Lane& L : c->lanes) {
+        if (L.deferred && (h_imgs_u8 == nullptr || L.def_dst == h_imgs_u8)) { int rc = flush_deferred(c, L); if (rc) return rc; }
         if (L.pending_copy && (h_imgs_u8 == nullptr || L.copy_dst == h_imgs_u8)) {
             RR_HIP(c, hipEventSynchronize(L.ev_copied));
             L.pending_copy = false; L.copy_dst = nullptr;
         }
+    }
     return 0;
 }
 
@@ -935,6 +990,7 @@ int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_ma
     rc = upload_tables(c); if (rc) return rc;
     const size_t li = c->next_lane++ % c->lanes.size();
     Lane& L = c->lanes[li];
+    { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     static_assert(sizeof(rr_material) == sizeof(float4), "rr_material is {velocity, ambient, diffuse, specular}");
@@ -1026,6 +1082,7 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
     const int A = c->cfg.n_angles;
     if (c->lanes.size() == 1) {
         Lane& L = c->lanes[0];
+        { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
         c->last_lane = 0;
         rc = run_frame(c, L, pose, 0, A, nullptr, nullptr, user); if (rc) return rc;
         return rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user);
@@ -1036,6 +1093,7 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
     // that assemble has consumed its columns.
     const size_t li = c->next_stream_lane++ % (size_t)c->stream_lanes;
     Lane& L = c->lanes[li];
+    { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(L.stream, L.ev_consumed, 0));
     rc = run_frame(c, L, pose, 0, A, nullptr, nullptr, L.stream); if (rc) return rc;
@@ -1051,6 +1109,7 @@ int rr_synchronize(rr_ctx* c, void* stream)
 {
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
+    for (Lane& L : c->lanes) { int rc = flush_deferred(c, L); if (rc) return rc; }
     for (Lane& L : c->lanes) RR_HIP(c, hipStreamSynchronize(L.stream));
     RR_HIP(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
     // batches may run on OTHER caller streams as well (the header recommends four): a frame there could set a
@@ -1109,6 +1168,7 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
     if (n_seg == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return 0; }
     rc = upload_tables(c); if (rc) return rc;
     Lane& L = c->lanes[0];
+    { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = 0;
     RR_HIP(c, hipDeviceSynchronize());
     rc = run_frame(c, L, pose, az_begin, az_end, nullptr, nullptr, c->stream, 1, nullptr, 0, out_f32 != nullptr);

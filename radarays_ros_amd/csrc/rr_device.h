@@ -132,6 +132,10 @@ struct Params {
     double noise_at_0, noise_at_1, noise_e_max, noise_e_min, noise_e_loss;
     int spill_stride, stack_lds, spill_depth;
     int pass0_az;                // pass 0: neighbouring segments per wave (power of two <= 16); 16 / pass0_az samples each
+    // host delivery folded into the later-pass trace launches (rr_simulate_batch_host_async): row 0 of such a grid is
+    // not rays -- its first copy_blocks workgroups trickle a slice of the images the lane's PREVIOUS batch left in
+    // device memory to page-locked host memory, one 1-KB store per wave in flight
+    const uint4* copy_src; uint4* copy_dst; unsigned long long copy_n16; int copy_blocks;
 };
 
 static_assert(sizeof(Params) <= 4096, "Params is passed by value: HIP kernel arguments are limited to 4 KB");

@@ -229,13 +229,30 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     // so the waves that run at the same time are neighbours in azimuth: k_trace 128 us (round 1: Morton
     // order of the samples inside one azimuth, azimuth after azimuth) -> 80 us per 640k rays at config 2.
     // Every wave is full, too (200 rays per azimuth would otherwise leave a 13th wave with 8 rays)
-    const int count = FIRST ? 0 : (int)P.count[cur][blockIdx.y];
+    // later passes may carry a host copy in row 0 of the grid (see Params::copy_src)
+    const int row0 = FIRST ? 0 : (P.copy_blocks > 0 ? 1 : 0);
+    if (!FIRST && row0 && blockIdx.y == 0) {
+        if ((int)blockIdx.x < P.copy_blocks) {
+            __builtin_amdgcn_s_setprio(0);
+            const size_t nthreads = (size_t)P.copy_blocks * kTraceThreads;
+            for (size_t i = (size_t)blockIdx.x * kTraceThreads + threadIdx.x; i < P.copy_n16; i += nthreads) {
+                const uint4 v = P.copy_src[i];
+                P.copy_dst[i] = v;
+                // ONE store per wave in flight: the writes leave at the pace PCIe takes them instead of filling the
+                // memory pipeline's write queues, where the stores of every other kernel would wait behind them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        return;
+    }
+    const int seg_y = (int)blockIdx.y - row0;
+    const int count = FIRST ? 0 : (int)P.count[cur][seg_y];
     if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
     __shared__ int s_seg[kRaysPerBlock];
     if (threadIdx.x < kRaysPerBlock) {
         const int rr = threadIdx.x;
         int k = blockIdx.x * kRaysPerBlock + rr;           // trace slot
-        int seg = blockIdx.y;
+        int seg = seg_y;
         bool live = k < count;
         if (FIRST) {
             // wave w = tile (sample block sb, azimuth block ab) of (16 / A) samples x A neighbouring segments
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         R.o = { s_ray[0][r], s_ray[1][r], s_ray[2][r] }; R.d = { s_ray[3][r], s_ray[4][r], s_ray[5][r] };
         R.idx = s_ray[6][r]; R.idy = s_ray[7][r]; R.idz = s_ray[8][r];
         R.oox = s_ray[9][r]; R.ooy = s_ray[10][r]; R.ooz = s_ray[11][r];
-        const int gray = (blockIdx.y * gridDim.x + blockIdx.x) * kRaysPerBlock + r;
+        const int gray = ((FIRST ? 0 : seg_y) * (int)gridDim.x + (int)blockIdx.x) * kRaysPerBlock + r;   // spill column of this ray slot
         const Hit h = traverse<STATS, SPILL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
@@ -1117,13 +1134,16 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     // read their segment's count and exit)
     const long bound = std::min<long>((long)P.cap, pass < 20 ? (long)P.n_beam << pass : (long)P.cap);
     dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + 1) / 2))
-                          : dim3((unsigned)((bound + kRaysPerBlock - 1) / kRaysPerBlock), n_seg);
+                          : dim3((unsigned)((bound + kRaysPerBlock - 1) / kRaysPerBlock), n_seg + (P.copy_blocks > 0 ? 1 : 0));
+    Params Pl = P;
+    if (pass == 0) Pl.copy_blocks = 0;
+    else Pl.copy_blocks = std::min<int>(P.copy_blocks, (int)grid.x);      // the copy's workgroups are the first of row 0
     dim3 block(kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
     // rocprofv3 reports), not the time the launch spent waiting for CUs held by other streams
-#define RR_LAUNCH_TRACE(F, S, X) hipExtLaunchKernelGGL((k_trace<F, S, X>), grid, block, lds, s, ev_start, ev_stop, 0, P, pass)
+#define RR_LAUNCH_TRACE(F, S, X) hipExtLaunchKernelGGL((k_trace<F, S, X>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass)
     if (pass == 0) {
         if (stats) { if (spill) RR_LAUNCH_TRACE(true, true, true); else RR_LAUNCH_TRACE(true, true, false); }
         else       { if (spill) RR_LAUNCH_TRACE(true, false, true); else RR_LAUNCH_TRACE(true, false, false); }

@@ -61,11 +61,17 @@ def test_multi_with_one_device_equals_rr_simulate(native_lib, small):
         native_lib.MultiContext([0, 977])
 
 
-def test_batch_host_async_delivers_the_same_images(native_lib, small):
-    """Images copied to page-locked host memory (copy ordered behind each batch on its stream), several batches in flight on two streams:
-    every image equals rr_simulate's; rr_wait_host(ptr) waits for exactly that buffer."""
+@pytest.mark.parametrize("fold_always", [False, True])
+def test_batch_host_async_delivers_the_same_images(native_lib, small, fold_always, monkeypatch):
+    """Images delivered to page-locked host memory, several batches in flight on two streams: every image equals
+    rr_simulate's; rr_wait_host(ptr) completes exactly that buffer.  A batch's images either leave with a plain copy or
+    wait on their lane and ride out on the trace launches of the lane's next batch (a few waves, one store in flight
+    each); the library picks by how many other batches are in flight -- `fold_always` forces the second way wherever it is
+    possible, so both are checked byte for byte."""
     import torch
     s, cfg, mats, beams, noise, poses = small
+    if fold_always:
+        monkeypatch.setenv("RR_FOLD_MIN_BUSY", "0")
     c = native_lib.Context(0)
     _setup(c, s, cfg, mats, beams, noise[0])
     ref = [c.simulate(p)[0] for p in poses]
