@@ -82,10 +82,11 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_consumed = nullptr;
     bool pending_consume = false;
-    // host delivery: the lane's device images are free again when ev_copied has passed
-    hipEvent_t ev_copied = nullptr;
-    bool pending_copy = false;
-    const void* copy_dst = nullptr;
+    // host delivery (rr_simulate_batch_host_async): the copies of this lane that may still be in flight.  Two records:
+    // a lane's copies complete in order, and a record is reused only after its copy has completed (take_rec waits), so a
+    // buffer that is in no record any more has been delivered.
+    struct CopyRec { const void* dst = nullptr; hipEvent_t ev = nullptr; bool pending = false; } rec[2];
+    int rec_next = 0;
     // a batch's images stay in d_img_u8 ("deferred") until the lane's NEXT host-delivery batch, whose later-pass trace
     // launches carry the copy (see Params::copy_src); rr_wait_host / rr_synchronize / any other use of the lane flush a
     // deferred copy with a plain hipMemcpyAsync
@@ -459,14 +460,27 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.pass0_az = c->pass0_az;
 }
 
+// a free copy record of the lane (waits for the oldest copy if both are still in flight)
+int take_rec(rr_ctx* c, Lane& L, Lane::CopyRec** out)
+{
+    Lane::CopyRec& r = L.rec[L.rec_next];
+    L.rec_next ^= 1;
+    if (r.pending) { RR_HIP(c, hipEventSynchronize(r.ev)); r.pending = false; r.dst = nullptr; }
+    *out = &r;
+    return 0;
+}
+
 // the lane's deferred host copy, now, as a plain copy on the stream its batch ran on
 int flush_deferred(rr_ctx* c, Lane& L)
 {
     if (!L.deferred) return 0;
+    Lane::CopyRec* r = nullptr;
+    int rc = take_rec(c, L, &r); if (rc) return rc;
     RR_HIP(c, hipMemcpyAsync(L.def_dst, L.d_img_u8.p, L.def_bytes, hipMemcpyDeviceToHost, L.def_stream));
-    RR_HIP(c, hipEventRecord(L.ev_copied, L.def_stream));
+    RR_HIP(c, hipEventRecord(r->ev, L.def_stream));
+    r->dst = L.def_dst; r->pending = true;
     RR_HIP(c, hipEventRecord(L.ev_consumed, L.def_stream));
-    L.pending_consume = true; L.pending_copy = true; L.copy_dst = L.def_dst;
+    L.pending_consume = true;
     L.deferred = false;
     return 0;
 }
@@ -631,7 +645,8 @@ rr_ctx* rr_create(int device)
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&L.ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.ev_consumed, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&L.ev_copied, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&L.rec[0].ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L.rec[1].ev, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "rr_create: lane stream/event creation failed"; rr_destroy(c); return nullptr;
         }
     }
@@ -655,7 +670,7 @@ void rr_destroy(rr_ctx* c)
         L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
-        if (L.ev_copied) (void)hipEventDestroy(L.ev_copied);
+        for (Lane::CopyRec& r : L.rec) if (r.ev) (void)hipEventDestroy(r.ev);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -919,7 +934,11 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     const bool fold = L.deferred && L.def_foldable && c->copy_blocks > 0 && g.n_reflections >= 2 && L.def_bytes % 16 == 0 &&
                       L.d_img_u8.n >= bytes && !c->stats_mode && busy >= c->fold_min_busy;
     const uint8_t* job_src = nullptr; uint8_t* job_dst = nullptr; size_t job_bytes = 0;
-    if (fold) { job_src = L.d_img_u8.p; job_dst = L.def_dst; job_bytes = L.def_bytes; L.deferred = false; }
+    Lane::CopyRec* rec = nullptr;
+    if (fold) {
+        rc = take_rec(c, L, &rec); if (rc) return rc;
+        job_src = L.d_img_u8.p; job_dst = L.def_dst; job_bytes = L.def_bytes; L.deferred = false;
+    }
     else { rc = flush_deferred(c, L); if (rc) return rc; if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0)); }
     if (L.d_img_u8.n < bytes) {
         RR_HIP(c, hipDeviceSynchronize());      // an earlier copy may still read the old buffer
@@ -929,11 +948,11 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     if (rc) {
         if (fold) {     // the frame was refused before any launch: the folded copy still has to happen
             RR_HIP(c, hipMemcpyAsync(job_dst, job_src, job_bytes, hipMemcpyDeviceToHost, s));
-            RR_HIP(c, hipEventRecord(L.ev_copied, s)); L.pending_copy = true; L.copy_dst = job_dst;
+            RR_HIP(c, hipEventRecord(rec->ev, s)); rec->dst = job_dst; rec->pending = true;
         }
         return rc;
     }
-    if (fold) { RR_HIP(c, hipEventRecord(L.ev_copied, s)); L.pending_copy = true; L.copy_dst = job_dst; }   // behind the launches that carried it
+    if (fold) { RR_HIP(c, hipEventRecord(rec->ev, s)); rec->dst = job_dst; rec->pending = true; }   // behind the launches that carried it
     { TimedScope t(c, s, "assemble");
       launch_assemble_u8(L.d_cols_u8.p, L.d_img_u8.p, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
                          (size_t)g.n_angles * g.n_cells, n_frames, (size_t)g.n_angles * g.n_cells); }
@@ -963,10 +982,11 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
     RR_HIP(c, hipSetDevice(c->device));
     for (Lane& L : c->lanes) {
         if (L.deferred && (h_imgs_u8 == nullptr || L.def_dst == h_imgs_u8)) { int rc = flush_deferred(c, L); if (rc) return rc; }
-        if (L.pending_copy && (h_imgs_u8 == nullptr || L.copy_dst == h_imgs_u8)) {
-            RR_HIP(c, hipEventSynchronize(L.ev_copied));
-            L.pending_copy = false; L.copy_dst = nullptr;
-        }
+        for (Lane::CopyRec& r : L.rec)
+            if (r.pending && (h_imgs_u8 == nullptr || r.dst == h_imgs_u8)) {
+                RR_HIP(c, hipEventSynchronize(r.ev));
+                r.pending = false; r.dst = nullptr;
+            }
     }
     return 0;
 }
@@ -1116,7 +1136,7 @@ int rr_synchronize(rr_ctx* c, void* stream)
     // bit between the read and the clear below, so the whole device is drained first -- after this call no
     // frame of this context is in flight anywhere and every error bit raised so far is reported exactly once
     RR_HIP(c, hipDeviceSynchronize());
-    for (Lane& L : c->lanes) { L.pending_copy = false; L.copy_dst = nullptr; }
+    for (Lane& L : c->lanes) for (Lane::CopyRec& r : L.rec) { r.pending = false; r.dst = nullptr; }
     // error bits of every frame the asynchronous entry points enqueued since the last call (a frame that
     // overflowed its wave queue or met a bad material id is truncated, never silently)
     uint32_t bits = 0;

@@ -76,20 +76,22 @@ def test_batch_host_async_delivers_the_same_images(native_lib, small, fold_alway
     _setup(c, s, cfg, mats, beams, noise[0])
     ref = [c.simulate(p)[0] for p in poses]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    bufs = [native_lib.HostImages((3, cfg.n_cells, 400)) for _ in range(6)]
+    NB = 14                                  # 14 batches over 4 lanes: every lane is reused three times, its copy records too
+    bufs = [native_lib.HostImages((3, cfg.n_cells, 400)) for _ in range(NB)]
     for b in bufs:
         b.array[:] = 7
-    order = []
-    for k in range(6):                       # 6 batches of 3 poses, more batches than lanes (4): lanes are reused
+    for k in range(NB):
         ps = [poses[(k + j) % 6] for j in range(3)]
         c.simulate_batch_host_async(ps, bufs[k].ptr, streams[k % 2].cuda_stream)
-        order.append(ps)
-    c.wait_host(bufs[0].ptr)
-    for j in range(3):
-        assert np.array_equal(bufs[0].array[j], ref[j % 6])
+    # buffers are waited for one by one, the oldest (whose record has long been reused) and the newest (still deferred on
+    # its lane) first: each must be complete when its own wait returns, whatever the others are doing
+    for k in (0, NB - 1, 5, 9, 1, 12, 4):
+        c.wait_host(bufs[k].ptr)
+        for j in range(3):
+            assert np.array_equal(bufs[k].array[j], ref[(k + j) % 6]), (k, j)
     c.wait_host(None)
     c.synchronize()
-    for k in range(6):
+    for k in range(NB):
         for j in range(3):
             assert np.array_equal(bufs[k].array[j], ref[(k + j) % 6]), (k, j)
     # pageable memory works too (the copy then simply does not overlap)
