@@ -49,6 +49,23 @@ def run(iters=20, seed=0, verbose=True):
         c.simulate_batch_device(poses, imgs.data_ptr(), sp)
         c.synchronize(sp); torch.cuda.synchronize()
         if not np.array_equal(imgs.cpu().numpy(), ref): what.append("batch_device")
+        # (b3) host delivery: 5..9 batches of the K poses (rotated) on two streams, so that lanes and their copy records
+        # are reused; interleaved at random with a device-path batch on the same lanes (which must flush what waits
+        # there); waits in random order.  RR_FOLD_MIN_BUSY=0 (set by the caller's environment) forces the folded route
+        NB = int(rs.randint(5, 10))
+        st2 = torch.cuda.Stream(device=dev)
+        hosts = [native.HostImages((K, C, 400)) for _ in range(NB)]
+        for h in hosts: h.array[:] = 9
+        for b in range(NB):
+            ps = np.roll(poses, -b, axis=0)
+            c.simulate_batch_host_async(ps, hosts[b].ptr, (sp, st2.cuda_stream)[b % 2])
+            if rs.randint(0, 4) == 0:
+                c.simulate_batch_device(poses, imgs.data_ptr(), sp)
+        for b in rs.permutation(NB):
+            c.wait_host(hosts[int(b)].ptr)
+            if not np.array_equal(hosts[int(b)].array, np.roll(ref, -int(b), axis=0)): what.append("host_async[%d of %d]" % (int(b), NB)); break
+        c.synchronize(sp); torch.cuda.synchronize()
+        for h in hosts: h.close()
         # (c) sharded: W ranks' blocks of one frame, assembled from [rank][n_loc][C]
         W = int(rs.choice([2, 4, 8])); nl = 400 // W
         blocks = torch.zeros((W, nl, C), dtype=torch.uint8, device=dev); one = torch.zeros((C, 400), dtype=torch.uint8, device=dev)
