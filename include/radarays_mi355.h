@@ -189,7 +189,8 @@ int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint
  * images left in HBM, where a plain copy behind each batch costs 7 %); rr_wait_host / rr_synchronize / any other use of
  * the lane send what is still waiting with a plain copy.  Issue batches on up to four streams (HIP maps streams onto
  * four hardware queues) and hand the buffers out from a ring twice as deep as the batches in flight.  h_imgs_u8
- * should be page-locked (rr_host_alloc / rr_host_free = hipHostMalloc); a pageable buffer works through the plain copy. */
+ * should be page-locked (rr_host_alloc / rr_host_free = hipHostMalloc); a pageable buffer works through the plain copy.
+ * rr_destroy drops images that nobody waited for. */
 int rr_simulate_batch_host_async(rr_ctx* ctx, const float* poses, int n_frames, uint8_t* h_imgs_u8, void* stream);
 int rr_wait_host(rr_ctx* ctx, const void* h_imgs_u8);
 void* rr_host_alloc(size_t bytes);
