@@ -66,10 +66,11 @@ struct Lane {
     int buf_seg = 0, buf_cap = 0, buf_sigcap = 0, buf_cells = 0;
     DevBuf<float4> d_wA[2], d_wB[2];
     DevBuf<double2> d_wC[2];
-    DevBuf<uint32_t> d_idx[2], d_count[2], d_torder[2], d_refpos, d_hit_tri, d_sig_count, d_spill;
+    DevBuf<uint32_t> d_idx[2], d_count[2], d_torder[2], d_refpos, d_sig_count, d_spill;
+    DevBuf<uint2> d_hit;
     DevBuf<uint8_t> d_cflag, d_cols_u8;
     DevBuf<SigRec> d_sigtmp, d_sig;
-    DevBuf<float> d_hit_t, d_cols_f32;
+    DevBuf<float> d_cols_f32;
     DevBuf<Counters> d_counters;
     DevBuf<uint32_t> d_sticky;    // error bits of ALL frames since the last rr_synchronize (async entry points); the synchronous entry points clear them when they report an error themselves
     DevBuf<uint8_t> d_img_u8;     // host-buffer path: assembled image before the D2H copy
@@ -374,8 +375,7 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     RR_HIP(c, L.d_cflag.ensure(S * 2 * cap));
     RR_HIP(c, L.d_refpos.ensure(S * 2 * cap));
     RR_HIP(c, L.d_sigtmp.ensure(S * 2 * cap));
-    RR_HIP(c, L.d_hit_t.ensure(S * cap));
-    RR_HIP(c, L.d_hit_tri.ensure(S * cap));
+    RR_HIP(c, L.d_hit.ensure(S * cap));
     RR_HIP(c, L.d_sig.ensure(S * sigcap));
     RR_HIP(c, L.d_sig_count.ensure(S));
     if (!L.d_counters.p) { RR_HIP(c, L.d_counters.ensure(1)); RR_HIP(c, hipMemset(L.d_counters.p, 0, sizeof(Counters))); }
@@ -433,7 +433,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
         P.idx[k] = L.d_idx[k].p; P.count[k] = L.d_count[k].p; P.torder[k] = L.d_torder[k].p;
     }
     P.refpos = L.d_refpos.p;
-    P.cflag = L.d_cflag.p; P.sigtmp = L.d_sigtmp.p; P.hit_t = L.d_hit_t.p; P.hit_tri = L.d_hit_tri.p;
+    P.cflag = L.d_cflag.p; P.sigtmp = L.d_sigtmp.p; P.hit = L.d_hit.p;
     P.sig = L.d_sig.p; P.sig_count = L.d_sig_count.p; P.spill = L.d_spill.p; P.counters = L.d_counters.p; P.sticky = L.d_sticky.p; P.seg_stats = L.d_seg_stats.p;
     P.cols_u8 = d_cols_u8; P.cols_f32 = d_cols_f32;
     P.q_sm = { pose[0], pose[1], pose[2], pose[3] };
@@ -666,8 +666,8 @@ void rr_destroy(rr_ctx* c)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
         L.d_refpos.release();
-        L.d_hit_tri.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
-        L.d_sigtmp.release(); L.d_sig.release(); L.d_hit_t.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
+        L.d_hit.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
+        L.d_sigtmp.release(); L.d_sig.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         for (Lane::CopyRec& r : L.rec) if (r.ev) (void)hipEventDestroy(r.ev);

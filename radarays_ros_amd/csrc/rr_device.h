@@ -103,8 +103,7 @@ struct Params {
     uint32_t* refpos;            // [n_seg][2*cap] child slot -> its position in the next pass' idx
     uint8_t* cflag;              // [n_seg][2*cap] child alive flags (+ bit2 on slot 2j: hit)
     SigRec* sigtmp;              // [n_seg][2*cap] per-wave signal slots (path, air)
-    float* hit_t;                // [n_seg][cap]
-    uint32_t* hit_tri;           // [n_seg][cap]
+    uint2* hit;                  // [n_seg][cap] nearest hit of a wave: (range as float bits, or -1.0f for a miss; leaf-order triangle index): ONE 8-B store per ray
     SigRec* sig;                 // [n_seg][sigcap] ordered signal list
     uint32_t* sig_count;         // [n_seg]
     uint32_t* spill;             // traversal stack spill [depth][threads]

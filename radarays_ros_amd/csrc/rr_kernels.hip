@@ -133,7 +133,9 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
             const float ay = __builtin_fmaf(A.y, idy, ooy), by = __builtin_fmaf(B.x, idy, ooy);
             const float az = __builtin_fmaf(A.z, idz, ooz), bz = __builtin_fmaf(B.y, idz, ooz);
             const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
+            // (no safety factor on tmax: every box is padded by 2e-5 x the scene extent on each side, orders of magnitude
+            // more than the rounding of the six FMAs, so a flat box still has tmin < tmax for any ray that touches it)
+            const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
             // tmin <= min(tmax, tcull) as ONE compare (its mask is the ballot below).  tcull >= 0, so the
             // signed-integer minimum of the two bit patterns is the float minimum whenever tmax >= 0 and
             // a negative value (-> no hit, tmin >= 0) whenever tmax < 0
@@ -308,8 +310,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
                                        P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
-            P.hit_t[hk] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
-            P.hit_tri[hk] = h.tri;
+            P.hit[hk] = make_uint2(__float_as_uint((h.tri != 0xFFFFFFFFu) ? h.t : -1.0f), h.tri);
         }
     }
     if (STATS) {
@@ -497,11 +498,12 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
 
     // material sets: all frames share the rays of pass 0, traced once for frame 0
     const size_t hk = (size_t)((FIRST && P.share_first) ? seg % P.n_loc : seg) * P.cap + j;
-    const float range = P.hit_t[hk];
+    const uint2 hitrec = P.hit[hk];
+    const float range = __uint_as_float(hitrec.x);
     if (range >= 0.0f)   // miss => the wave dies silently (RadarCPU.cpp:252-255)
     {
         f0 |= 4;
-        const uint32_t tri = P.hit_tri[hk];
+        const uint32_t tri = hitrec.y;
         const float4* tp = reinterpret_cast<const float4*>(P.tris + tri);
         const float4 tb = tp[1], tc = tp[2];
         const uint32_t obj_id = __float_as_uint(tb.w);

@@ -61,7 +61,6 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
                     const float a = std::fma(ch.lo[k], inv[k], oo[k]), b = std::fma(ch.hi[k], inv[k], oo[k]);
                     tn = std::max(tn, std::min(a, b)); tf = std::min(tf, std::max(a, b));
                 }
-                tf *= 1.0000004f;
                 if (tn <= std::min(tf, tcull) && ch.ref != kEmptyRef) {
                     uint32_t bits; memcpy(&bits, &tn, 4);
                     key[nh] = (bits & ~3u) | (uint32_t)q; ref[nh] = ch.ref; nh++;
