@@ -119,6 +119,11 @@ int rr_set_mesh_gpu(rr_ctx* ctx, const float* verts /*[nv][3]*/, size_t nv,
                     const uint32_t* faces /*[nf][3]*/, size_t nf,
                     const uint32_t* face_object_id /*[nf] or NULL*/);
 
+/* The finished tree of `src` (either builder), copied device to device into `ctx` -- `ctx` may sit on another GPU
+ * (hipMemcpyPeer over xGMI) or on the same one.  What rr_multi_set_mesh uses to replicate the map after ONE build
+ * (radar_simulator.cpp:149 loads the map once per process).  Both contexts are drained first; `src` keeps its tree. */
+int rr_copy_mesh(rr_ctx* ctx, rr_ctx* src);
+
 /* Radar::loadParams (Radar.cpp:220-226): materials, object_materials,
  * material_id_air. */
 int rr_set_materials(rr_ctx* ctx, const rr_material* materials, size_t n_materials,
@@ -289,7 +294,9 @@ void rr_partition(int n_angles, int world, int rank, int* begin, int* end);
 int rr_multi_plan(int n_angles, int n_cells, int n_devices, int n_frames, int* equal_blocks, size_t* bytes_per_device,
                   size_t* send_off, size_t* recv_off, size_t* piece_bytes);
 /* replicated setters: same contracts as the rr_set_* calls above, applied to every device */
+/* rr_multi_set_mesh / _gpu: the tree is built ONCE (on the host / on device 0) and copied to the other devices (rr_copy_mesh) */
 int rr_multi_set_mesh(rr_multi* m, const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object_id);
+int rr_multi_set_mesh_gpu(rr_multi* m, const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object_id);
 int rr_multi_set_materials(rr_multi* m, const rr_material* materials, size_t n_materials,
                            const int32_t* object_materials, size_t n_objects, int32_t material_id_air);
 int rr_multi_set_config(rr_multi* m, const rr_config* cfg);

@@ -753,6 +753,30 @@ int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* fa
     return 0;
 }
 
+int rr_copy_mesh(rr_ctx* c, rr_ctx* src)
+{
+    if (!c) return -1;
+    if (!src || src == c) return fail(c, -3, "rr_copy_mesh: need another context as the source");
+    if (!src->have_mesh) return fail(c, -2, "rr_copy_mesh: the source context has no mesh");
+    // nothing may still trace the old tree here, nothing may still write the source's
+    RR_HIP(c, hipSetDevice(src->device));
+    RR_HIP(c, hipDeviceSynchronize());
+    RR_HIP(c, hipSetDevice(c->device));
+    RR_HIP(c, hipDeviceSynchronize());
+    const size_t n4 = (size_t)src->n_nodes * 8 + ((size_t)src->n_tris + 4) * 3;     // float4 records, as rr_set_mesh sizes them
+    c->have_mesh = false;
+    for (Lane& L : c->lanes) L.buf_seg = 0;
+    RR_HIP(c, c->d_bvh.ensure(n4));
+    // child references are offsets from the base of the allocation: the tree is position independent
+    if (src->device == c->device) RR_HIP(c, hipMemcpy(c->d_bvh.p, src->d_bvh.p, n4 * sizeof(float4), hipMemcpyDeviceToDevice));
+    else RR_HIP(c, hipMemcpyPeer(c->d_bvh.p, c->device, src->d_bvh.p, src->device, n4 * sizeof(float4)));
+    RR_HIP(c, hipDeviceSynchronize());
+    c->tri_base4 = src->tri_base4; c->n_nodes = src->n_nodes; c->n_tris = src->n_tris;
+    c->depth = src->depth; c->stack_need = src->stack_need;
+    c->have_mesh = true;
+    return 0;
+}
+
 int rr_set_materials(rr_ctx* c, const rr_material* materials, size_t n_materials,
                      const int32_t* object_materials, size_t n_objects, int32_t material_id_air)
 {
@@ -1104,8 +1128,13 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
         Lane& L = c->lanes[0];
         { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
         c->last_lane = 0;
+        // the lane's previous frame may have run on ANOTHER caller stream (or a flushed host copy may still read the lane)
+        if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(user, L.ev_consumed, 0));
         rc = run_frame(c, L, pose, 0, A, nullptr, nullptr, user); if (rc) return rc;
-        return rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user);
+        rc = rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user); if (rc) return rc;
+        RR_HIP(c, hipEventRecord(L.ev_consumed, user));
+        L.pending_consume = true;
+        return 0;
     }
     // Frame pipelining: trace/shade/scan/column of this frame run on the lane's own stream
     // (no dependency on the caller's stream), only the assemble -- the one kernel that touches

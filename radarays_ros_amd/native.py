@@ -15,7 +15,7 @@ _LIB = None
 
 SYMBOLS = [
     "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
-    "rr_set_mesh", "rr_set_mesh_gpu", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
+    "rr_set_mesh", "rr_set_mesh_gpu", "rr_copy_mesh", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
     "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device", "rr_simulate_batch_columns_device",
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
@@ -23,7 +23,7 @@ SYMBOLS = [
     "rr_get_kernel_time", "rr_get_kernel_samples", "rr_reserve_timing_events",
     "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_partition", "rr_multi_plan",
     "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_ctx",
-    "rr_multi_set_mesh", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
+    "rr_multi_set_mesh", "rr_multi_set_mesh_gpu", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
     "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
 ]
 
@@ -99,6 +99,7 @@ def lib():
     L.rr_last_error.argtypes = [vp]
     L.rr_set_mesh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
     L.rr_set_mesh_gpu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.rr_copy_mesh.argtypes = [vp, vp]
     L.rr_set_materials.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int32]
     L.rr_set_config.argtypes = [vp, C.POINTER(RRConfig)]
     L.rr_set_beam_samples.argtypes = [vp, vp, C.c_size_t]
@@ -143,6 +144,7 @@ def lib():
     L.rr_multi_ctx.restype = vp
     L.rr_multi_ctx.argtypes = [vp, C.c_int]
     L.rr_multi_set_mesh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.rr_multi_set_mesh_gpu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
     L.rr_multi_set_materials.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int32]
     L.rr_multi_set_config.argtypes = [vp, C.POINTER(RRConfig)]
     L.rr_multi_set_beam_samples.argtypes = [vp, vp, C.c_size_t]
@@ -226,6 +228,10 @@ class Context:
             raise ValueError("face_object_id must have one entry per face")
         fn = {"host": self._L.rr_set_mesh, "gpu": self._L.rr_set_mesh_gpu}[builder]
         self._ck(fn(self._h, v.ctypes.data, len(v), f.ctypes.data, len(f), None if o is None else o.ctypes.data))
+
+    def copy_mesh(self, src):
+        """take the finished tree of another context (same or another device): rr_copy_mesh"""
+        self._ck(self._L.rr_copy_mesh(self._h, src._h))
 
     def set_materials(self, materials, object_materials, material_id_air=0):
         m = (RRMaterial * len(materials))(*[RRMaterial(*[float(x) for x in (t.astuple() if hasattr(t, "astuple") else t)])
@@ -447,11 +453,12 @@ class MultiContext:
     def device_count(self):
         return self._L.rr_multi_device_count(self._h)
 
-    def set_mesh(self, verts, faces, face_object_id=None):
+    def set_mesh(self, verts, faces, face_object_id=None, builder="host"):
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
         o = None if face_object_id is None else np.ascontiguousarray(face_object_id, np.uint32)
-        self._ck(self._L.rr_multi_set_mesh(self._h, v.ctypes.data, len(v), f.ctypes.data, len(f), None if o is None else o.ctypes.data))
+        fn = {"host": self._L.rr_multi_set_mesh, "gpu": self._L.rr_multi_set_mesh_gpu}[builder]
+        self._ck(fn(self._h, v.ctypes.data, len(v), f.ctypes.data, len(f), None if o is None else o.ctypes.data))
 
     def set_materials(self, materials, object_materials, material_id_air=0):
         m = (RRMaterial * len(materials))(*[RRMaterial(*[float(x) for x in (t.astuple() if hasattr(t, "astuple") else t)])

@@ -168,3 +168,29 @@ def test_waves_at_the_pruning_threshold(native_lib, oracle, seed):
         assert abs(gst[k] - ost[k]) <= slack, (k, gst, ost, near)
     d = image_diff(gf, of, g8, o8)
     assert d["mean_dev"] <= (1e-5 if near == 0 else 1e-4) and d["u8_max"] <= 1, (d, near)
+
+
+def test_copy_mesh_replicates_a_finished_tree(native_lib, small):
+    """rr_copy_mesh (what rr_multi_set_mesh uses after ONE build): the copy renders the same bytes as the source, for
+    either builder, stays valid after the source is gone, and a context without a mesh is refused as a source."""
+    s, cfg, mats, beams, noise, poses = small
+    for builder in ("host", "gpu"):
+        a = native_lib.Context(0)
+        a.set_mesh(s["verts"], s["faces"], s["face_object_id"], builder=builder)
+        a.set_materials(mats, s["object_materials"], 0); a.set_config(cfg, 400); a.set_beam_samples(beams); a.set_noise_offsets(noise[0])
+        ref, _, st = a.simulate(poses[1])
+        b = native_lib.Context(0)
+        with pytest.raises(native_lib.RRError, match="need another context"):
+            b.copy_mesh(b)
+        b.copy_mesh(a)
+        assert b.bvh_info() == a.bvh_info()
+        a.close()
+        b.set_materials(mats, s["object_materials"], 0); b.set_config(cfg, 400); b.set_beam_samples(beams); b.set_noise_offsets(noise[0])
+        got, _, st2 = b.simulate(poses[1])
+        assert np.array_equal(got, ref) and st2["wave_passes"] == st["wave_passes"]
+        e = native_lib.Context(0)
+        with pytest.raises(native_lib.RRError, match="source context has no mesh"):
+            b.copy_mesh(e)
+        got2, _, _ = b.simulate(poses[1])          # a refused copy leaves the tree in place
+        assert np.array_equal(got2, ref)
+        b.close(); e.close()
