@@ -58,6 +58,11 @@ struct Hit { float t; uint32_t tri; uint32_t face; };
 constexpr int kRaysPerWave = 16;
 constexpr int kTraceThreads = 128;                       // 32 rays per workgroup (measured: 64/128 threads beat 256/512 -- a workgroup holds its LDS until its slowest wave is done)
 constexpr int kRaysPerBlock = kTraceThreads / 4;
+#ifndef RR_CULL_POP
+#define RR_CULL_POP 1
+#endif
+constexpr bool kCullPop = RR_CULL_POP != 0;   // later passes: stack entries carry a 16-bit lower bound of their entry distance (6 B per entry)
+constexpr size_t kHandoffBytes = 14 * kRaysPerBlock * 4;    // k_trace: 12 floats + 2 ints per ray, aliased with the stack
 
 #define RR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true)
 #define RR_DPP_F(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xF, 0xF, true))
@@ -88,7 +93,7 @@ __device__ inline RaySetup ray_setup(V3 o, V3 d)
     return R;
 }
 
-template <bool STATS, bool SPILL>
+template <bool STATS, bool SPILL, bool CULL>
 __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t tri_base4,
                                const RaySetup& R, float range_max,
                                uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gray,
@@ -98,6 +103,10 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
     const int wave = threadIdx.x >> 6;
     const int rw = (threadIdx.x & 63) >> 2;                         // ray within the wave
     uint32_t* my = lds_stack + (size_t)wave * stack_lds * kRaysPerWave + rw;   // entry e at my[e*16]
+    // beside every reference: the upper 16 bits of the entry distance of its box (truncated, i.e. a lower bound).  An
+    // entry whose bound lies beyond the cull distance by the time it is popped is dropped without fetching the node
+    uint16_t* myk = reinterpret_cast<uint16_t*>(lds_stack + (size_t)(kTraceThreads / 64) * stack_lds * kRaysPerWave) +
+                    (size_t)wave * stack_lds * kRaysPerWave + rw;
     const V3 o = R.o, d = R.d;
     const float idx = R.idx, idy = R.idy, idz = R.idz, oox = R.oox, ooy = R.ooy, ooz = R.ooz;
 
@@ -160,7 +169,7 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
             if (h && rank > 0) {
                 const int e = sp + (nhit - 1 - rank);
                 if (SPILL && e >= stack_lds) spill[(size_t)(e - stack_lds) * spill_stride + gray] = myref;
-                else my[e * kRaysPerWave] = myref;
+                else { my[e * kRaysPerWave] = myref; if (CULL) myk[e * kRaysPerWave] = (uint16_t)(__float_as_uint(tmin) >> 16); }
             }
             if (nhit > 0) { sp += nhit - 1; cur = nxt; continue; }
         } else {
@@ -197,9 +206,25 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
         }
         // pop
         if (STATS) n_tris += 0x10000u;   // high half: loop iterations of this lane
-        if (sp == 0) break;
-        sp--;
-        cur = (SPILL && sp >= stack_lds) ? spill[(size_t)(sp - stack_lds) * spill_stride + gray] : my[sp * kRaysPerWave];
+        if (!CULL) {
+            if (sp == 0) break;
+            sp--;
+            cur = (SPILL && sp >= stack_lds) ? spill[(size_t)(sp - stack_lds) * spill_stride + gray] : my[sp * kRaysPerWave];
+        } else {
+            // truncation is monotone: key(tmin) > key(tcull) implies tmin > tcull, the very test the node's own visit
+            // would fail for every child (their entry distances are not below the parent's)
+            const uint32_t ck = __float_as_uint(tcull) >> 16;
+            bool more = false;
+            while (sp > 0) {
+                sp--;
+                uint32_t k = 0;
+                if (SPILL && sp >= stack_lds) cur = spill[(size_t)(sp - stack_lds) * spill_stride + gray];
+                else { cur = my[sp * kRaysPerWave]; k = myk[sp * kRaysPerWave]; }
+                asm volatile("" : "+v"(cur), "+v"(k));      // both reads in ONE LDS round trip (the reference is not fetched after the test)
+                if (k <= ck) { more = true; break; }
+            }
+            if (!more) break;
+        }
     }
     Hit best;
     best.t = __uint_as_float((uint32_t)(bestkey >> 32));
@@ -218,9 +243,11 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     __builtin_amdgcn_s_setprio(2);
     extern __shared__ uint32_t lds_stack[];
     // prepared rays of the workgroup, one per lane of wave 0 (a quad would otherwise repeat the
-    // pose algebra four times and every wave would issue it for just 16 rays)
-    __shared__ float s_ray[12][kRaysPerBlock];
-    __shared__ int s_j[kRaysPerBlock];
+    // pose algebra four times and every wave would issue it for just 16 rays).  They are read once, before the
+    // traversal starts: the hand-off area is the bottom of the stack area (kHandoffBytes <= the launch's dynamic LDS)
+    float (*s_ray)[kRaysPerBlock] = reinterpret_cast<float (*)[kRaysPerBlock]>(lds_stack);
+    int* s_j = reinterpret_cast<int*>(lds_stack + 12 * kRaysPerBlock);
+    int* s_seg = s_j + kRaysPerBlock;
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int cur = pass & 1;
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
@@ -250,7 +277,6 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     const int seg_y = (int)blockIdx.y - row0;
     const int count = FIRST ? 0 : (int)P.count[cur][seg_y];
     if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
-    __shared__ int s_seg[kRaysPerBlock];
     if (threadIdx.x < kRaysPerBlock) {
         const int rr = threadIdx.x;
         int k = blockIdx.x * kRaysPerBlock + rr;           // trace slot
@@ -300,13 +326,14 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
 
     unsigned nn = 0, nt = 0;
     unsigned ws[4] = { 0, 0, 0, 0 };
+    RaySetup R;
+    R.o = { s_ray[0][r], s_ray[1][r], s_ray[2][r] }; R.d = { s_ray[3][r], s_ray[4][r], s_ray[5][r] };
+    R.idx = s_ray[6][r]; R.idy = s_ray[7][r]; R.idz = s_ray[8][r];
+    R.oox = s_ray[9][r]; R.ooy = s_ray[10][r]; R.ooz = s_ray[11][r];
+    __syncthreads();      // every ray has left the hand-off area: it is stack from here on
     if (active) {
-        RaySetup R;
-        R.o = { s_ray[0][r], s_ray[1][r], s_ray[2][r] }; R.d = { s_ray[3][r], s_ray[4][r], s_ray[5][r] };
-        R.idx = s_ray[6][r]; R.idy = s_ray[7][r]; R.idz = s_ray[8][r];
-        R.oox = s_ray[9][r]; R.ooy = s_ray[10][r]; R.ooz = s_ray[11][r];
         const int gray = ((FIRST ? 0 : seg_y) * (int)gridDim.x + (int)blockIdx.x) * kRaysPerBlock + r;   // spill column of this ray slot
-        const Hit h = traverse<STATS, SPILL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
+        const Hit h = traverse<STATS, SPILL, kCullPop && !FIRST>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
@@ -349,7 +376,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, c
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
     const RaySetup R = ray_setup(o, d);
-    const Hit h = traverse<false, true>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
+    const Hit h = traverse<false, true, kCullPop>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
     if ((threadIdx.x & 3) == 0) {
         out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
@@ -1141,7 +1168,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     if (pass == 0) Pl.copy_blocks = 0;
     else Pl.copy_blocks = std::min<int>(P.copy_blocks, (int)grid.x);      // the copy's workgroups are the first of row 0
     dim3 block(kTraceThreads);
-    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
+    const size_t lds = std::max((size_t)P.stack_lds * kRaysPerBlock * ((kCullPop && pass > 0) ? 6 : 4), kHandoffBytes);
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
     // rocprofv3 reports), not the time the launch spent waiting for CUs held by other streams
@@ -1204,7 +1231,7 @@ void launch_debug_trace(const Params& P, const float* origs, const float* dirs, 
                         float* out_t, uint32_t* out_face, hipStream_t s)
 {
     dim3 grid((n + kRaysPerBlock - 1) / kRaysPerBlock), block(kTraceThreads);
-    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * sizeof(uint32_t);
+    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * (kCullPop ? 6 : 4);
     hipLaunchKernelGGL(k_debug_trace, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
 }
 

@@ -97,7 +97,13 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
                 }
             }
         }
-        if (cull_pop) while (sp > 0 && stack_t[sp - 1] > tcull) sp--;
+        // what k_trace's later passes do: an entry carries the upper 16 bits of its box's entry distance (a lower bound);
+        // it is dropped at pop time when that bound lies beyond the cull distance (TREEQ_CULL_POP=exact: full precision)
+        if (cull_pop) {
+            static const bool exact = std::string(getenv("TREEQ_CULL_POP")) == "exact";
+            auto k16 = [](float x) { uint32_t b; memcpy(&b, &x, 4); return b >> 16; };
+            while (sp > 0 && (exact ? stack_t[sp - 1] > tcull : k16(stack_t[sp - 1]) > k16(tcull))) sp--;
+        }
         if (sp == 0) break;
         cur = stack[--sp];
     }
