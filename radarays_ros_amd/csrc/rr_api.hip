@@ -155,6 +155,7 @@ struct rr_ctx {
 
     bool roctx = false;
     int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
+    int cull_pop = 1;            // k_trace's later passes drop stack entries at pop time (RR_CULL_POP=0: off; the images are the same either way)
     int copy_blocks = 4;         // workgroups (2 waves each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
 };
 
@@ -458,6 +459,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.spill_stride = L.spill_stride; P.stack_lds = L.stack_lds;
     P.spill_depth = std::max(0, (int)c->stack_need - L.stack_lds);
     P.pass0_az = c->pass0_az;
+    P.cull_pop = c->cull_pop;
 }
 
 // a free copy record of the lane (waits for the oldest copy if both are still in flight)
@@ -639,6 +641,7 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_STACK_LDS")) c->stack_lds_max = std::max(1, std::min(64, atoi(getenv("RR_STACK_LDS"))));
     if (getenv("RR_ROCTX") && atoi(getenv("RR_ROCTX")) != 0) c->roctx = roctx_load();
     if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
+    if (getenv("RR_CULL_POP")) c->cull_pop = atoi(getenv("RR_CULL_POP")) != 0;
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(13, atoi(getenv("RR_COPY_BLOCKS"))));
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
@@ -1333,6 +1336,7 @@ int rr_debug_trace(rr_ctx* c, const float* origs, const float* dirs, size_t n, f
     P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
     P.tri_base4 = c->tri_base4; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
     P.spill = d_spill.p; P.spill_stride = (int)chunk; P.stack_lds = stack_lds; P.spill_depth = std::max(0, spill_depth);
+    P.cull_pop = c->cull_pop;
     int rc = 0;
     for (size_t b = 0; b < n && !rc; b += chunk) {
         const size_t m = std::min(chunk, n - b);

@@ -135,6 +135,7 @@ struct Params {
     // not rays -- its first copy_blocks workgroups trickle a slice of the images the lane's PREVIOUS batch left in
     // device memory to page-locked host memory, one 1-KB store per wave in flight
     const uint4* copy_src; uint4* copy_dst; unsigned long long copy_n16; int copy_blocks;
+    int cull_pop;            // later passes / rr_debug_trace: drop stack entries at pop time by their 16-bit distance bound (0: off, RR_CULL_POP=0)
 };
 
 static_assert(sizeof(Params) <= 4096, "Params is passed by value: HIP kernel arguments are limited to 4 KB");

@@ -235,7 +235,7 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
 }
 
 // grid: (ceil(cap/32), n_seg), block 128 (= 32 rays), dynamic LDS = 2 waves * stack_lds * 16 * 4
-template <bool FIRST, bool STATS, bool SPILL>
+template <bool FIRST, bool STATS, bool SPILL, bool CULL>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
 {
     // k_trace is the long pole of a step: its waves go first when they share a SIMD with the
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     __syncthreads();      // every ray has left the hand-off area: it is stack from here on
     if (active) {
         const int gray = ((FIRST ? 0 : seg_y) * (int)gridDim.x + (int)blockIdx.x) * kRaysPerBlock + r;   // spill column of this ray slot
-        const Hit h = traverse<STATS, SPILL, kCullPop && !FIRST>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
+        const Hit h = traverse<STATS, SPILL, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
@@ -366,6 +366,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
 }
 
 // generic rays (tests): one quad per ray
+template <bool CULL>
 __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, const float* origs, const float* dirs, int n,
                                                                float* out_t, uint32_t* out_face)
 {
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, c
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
     const RaySetup R = ray_setup(o, d);
-    const Hit h = traverse<false, true, kCullPop>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
+    const Hit h = traverse<false, true, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
     if ((threadIdx.x & 3) == 0) {
         out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
@@ -1168,17 +1169,24 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     if (pass == 0) Pl.copy_blocks = 0;
     else Pl.copy_blocks = std::min<int>(P.copy_blocks, (int)grid.x);      // the copy's workgroups are the first of row 0
     dim3 block(kTraceThreads);
-    const size_t lds = std::max((size_t)P.stack_lds * kRaysPerBlock * ((kCullPop && pass > 0) ? 6 : 4), kHandoffBytes);
+    // later passes cull stack entries at pop time (6-B entries) as long as 16 workgroups still fit a CU's 160 KB of LDS
+    // (10 KB each: up to 53 entries); a deeper tree keeps the 4-B entries -- the lost occupancy would cost more than the
+    // cull returns (GPU-built tree of the 10M-triangle target, 56 entries: 0.465 vs 0.442 ms per frame)
+    const bool cull = kCullPop && P.cull_pop && pass > 0 && (size_t)P.stack_lds * kRaysPerBlock * 6 <= 10240;
+    const size_t lds = std::max((size_t)P.stack_lds * kRaysPerBlock * (cull ? 6 : 4), kHandoffBytes);
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
     // rocprofv3 reports), not the time the launch spent waiting for CUs held by other streams
-#define RR_LAUNCH_TRACE(F, S, X) hipExtLaunchKernelGGL((k_trace<F, S, X>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass)
+#define RR_LAUNCH_TRACE(F, S, X, C) hipExtLaunchKernelGGL((k_trace<F, S, X, C>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass)
     if (pass == 0) {
-        if (stats) { if (spill) RR_LAUNCH_TRACE(true, true, true); else RR_LAUNCH_TRACE(true, true, false); }
-        else       { if (spill) RR_LAUNCH_TRACE(true, false, true); else RR_LAUNCH_TRACE(true, false, false); }
+        if (stats) { if (spill) RR_LAUNCH_TRACE(true, true, true, false); else RR_LAUNCH_TRACE(true, true, false, false); }
+        else       { if (spill) RR_LAUNCH_TRACE(true, false, true, false); else RR_LAUNCH_TRACE(true, false, false, false); }
+    } else if (cull) {
+        if (stats) { if (spill) RR_LAUNCH_TRACE(false, true, true, true); else RR_LAUNCH_TRACE(false, true, false, true); }
+        else       { if (spill) RR_LAUNCH_TRACE(false, false, true, true); else RR_LAUNCH_TRACE(false, false, false, true); }
     } else {
-        if (stats) { if (spill) RR_LAUNCH_TRACE(false, true, true); else RR_LAUNCH_TRACE(false, true, false); }
-        else       { if (spill) RR_LAUNCH_TRACE(false, false, true); else RR_LAUNCH_TRACE(false, false, false); }
+        if (stats) { if (spill) RR_LAUNCH_TRACE(false, true, true, false); else RR_LAUNCH_TRACE(false, true, false, false); }
+        else       { if (spill) RR_LAUNCH_TRACE(false, false, true, false); else RR_LAUNCH_TRACE(false, false, false, false); }
     }
 #undef RR_LAUNCH_TRACE
 }
@@ -1231,8 +1239,10 @@ void launch_debug_trace(const Params& P, const float* origs, const float* dirs, 
                         float* out_t, uint32_t* out_face, hipStream_t s)
 {
     dim3 grid((n + kRaysPerBlock - 1) / kRaysPerBlock), block(kTraceThreads);
-    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * (kCullPop ? 6 : 4);
-    hipLaunchKernelGGL(k_debug_trace, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
+    const bool cull = kCullPop && P.cull_pop;
+    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * (cull ? 6 : 4);
+    if (cull) hipLaunchKernelGGL(k_debug_trace<true>, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
+    else hipLaunchKernelGGL(k_debug_trace<false>, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
 }
 
 }  // namespace rr

@@ -130,6 +130,35 @@ def test_traversal_stack_spill_path(native_lib, oracle, monkeypatch):
         assert np.array_equal(t, t2) and np.array_equal(f, f2)
 
 
+def test_stack_cull_at_pop_is_invisible(native_lib, oracle, monkeypatch):
+    """k_trace's later passes drop stack entries whose 16-bit distance bound lies beyond the cull distance (RR_CULL_POP,
+    read at rr_create; default on).  The nearest hit is defined independently of the traversal order: frames (against the
+    oracle and against each other), statistics and nearest-hit queries are the same with the cull switched off -- fewer
+    nodes are visited with it on."""
+    s = scenes.heightfield_room(48, n_buildings=40, seed=11)
+    cfg = params.kaist_preset(n_reflections=4, ambient_noise=0)
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    pose = scenes.default_pose(s["name"])
+    rs = np.random.RandomState(9)
+    o = (rs.uniform(-150, 150, (4000, 3)) * np.array([1, 1, 0.02]) + np.array([0, 0, 8])).astype(np.float32)
+    d = rs.normal(size=(4000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RR_CULL_POP", mode)
+        _check(native_lib, oracle, s, cfg, mats, golden_beams(200), pose, az=(100, 130), use_bvh=1)
+        c = _ctx(native_lib, s, cfg, mats, golden_beams(200))
+        c.set_stats_mode(True)
+        img, _, st = c.simulate(pose)
+        res[mode] = (img, st, c.debug_trace(o, d))
+        c.close()
+    monkeypatch.delenv("RR_CULL_POP")
+    (i1, s1, (t1, f1)), (i0, s0, (t0, f0)) = res["1"], res["0"]
+    assert np.array_equal(i1, i0) and np.array_equal(t1, t0) and np.array_equal(f1, f0)
+    assert (s1["wave_passes"], s1["hits"], s1["signals"]) == (s0["wave_passes"], s0["hits"], s0["signals"])
+    assert s1["nodes_visited"] < 0.95 * s0["nodes_visited"]
+
+
 def test_cook_torrance_lobe_option(native_lib, oracle):
     """rr_config.brdf_model = 1 (BASELINE.json configs[4]; the build's own GGX / Smith specification -- the
     reference keeps its Cook-Torrance model on a branch outside the checkout, so this is parity UNPINNED):
