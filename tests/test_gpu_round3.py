@@ -56,6 +56,10 @@ def test_multi_with_one_device_equals_rr_simulate(native_lib, small):
     bad = np.array(poses[0]); bad[2] = np.nan
     with pytest.raises(native_lib.RRError, match="device 0: non-finite pose"):
         m.simulate(bad)
+    # the map built on device 0 by the GPU builder (rr_multi_set_mesh_gpu): same bytes (the nearest hit does not depend on the tree)
+    m.set_mesh(s["verts"], s["faces"], s["face_object_id"], builder="gpu")
+    c.set_noise_offsets(noise[0])
+    assert np.array_equal(m.simulate(poses[2]), c.simulate(poses[2])[0])
     m.close(); c.close()
     with pytest.raises(native_lib.RRError, match="device index out of range"):
         native_lib.MultiContext([0, 977])
