@@ -280,6 +280,8 @@ int rr_reserve_timing_events(rr_ctx* ctx, size_t n);
  * (ncclAllGather for equal blocks, a group of send/recv pairs for ragged ones), which transposes them into the
  * mono8 images and copies them to the caller's host buffer.  With one device no collective runs and the images
  * are byte-identical to rr_simulate's.  RCCL (librccl.so.1) is loaded at run time when n > 1. */
+/* (Test switch RR_MULTI_LOOPBACK=1: a device may be listed several times; the collective is then replaced by
+ * device-to-device copies along the same plan -- the n > 1 path on a one-GPU box, minus the RCCL calls.) */
 typedef struct rr_multi rr_multi;
 rr_multi* rr_create_multi(const int* devices, int n_devices);    /* NULL on failure: rr_multi_last_error(NULL) */
 void rr_destroy_multi(rr_multi* m);

@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -76,6 +77,7 @@ struct rr_multi {
     Buf<uint8_t> d_imgs;                  // root: [n_frames][n_cells][n_angles]
     rr_config cfg;
     bool have_cfg = false;
+    bool loopback = false;                // see rr_create_multi
     std::string err;
 };
 
@@ -101,9 +103,14 @@ extern "C" {
 rr_multi* rr_create_multi(const int* devices, int n_devices)
 {
     if (!devices || n_devices < 1 || n_devices > 64) { g_multi_create_error = "rr_create_multi: need 1..64 device indices"; return nullptr; }
-    for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++)
+    // RR_MULTI_LOOPBACK=1 (tests on a one-GPU box): a device may be listed several times; every listed entry gets its own
+    // context, block and stream as usual, and the ONE collective of a call is replaced by device-to-device copies that
+    // follow the same plan (rr_multi_plan) -- everything of the n > 1 path runs except the RCCL calls themselves
+    const bool loopback = getenv("RR_MULTI_LOOPBACK") && atoi(getenv("RR_MULTI_LOOPBACK")) != 0;
+    for (int i = 0; i < n_devices && !loopback; i++) for (int j = 0; j < i; j++)
         if (devices[i] == devices[j]) { g_multi_create_error = "rr_create_multi: a device is listed twice"; return nullptr; }
     rr_multi* m = new rr_multi();
+    m->loopback = loopback;
     m->devices.assign(devices, devices + n_devices);
     rr_default_config(&m->cfg);
     for (int i = 0; i < n_devices; i++) {
@@ -117,7 +124,7 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
         m->streams.push_back(s);
     }
     m->block.resize((size_t)n_devices); m->gathered.resize((size_t)n_devices);
-    if (n_devices > 1) {
+    if (n_devices > 1 && !loopback) {
         // the communicator is owned here: one rank per device of this process
         if (!g_rccl.load(g_multi_create_error)) { rr_destroy_multi(m); return nullptr; }
         m->comms.resize((size_t)n_devices, nullptr);
@@ -260,10 +267,17 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
     } else if (equal) {
         const size_t nl = (size_t)(e[0] - b[0]), per = (size_t)n_frames * nl * C;
         for (int i = 0; i < n; i++) { RRM_HIP(m, hipSetDevice(m->devices[(size_t)i])); RRM_HIP(m, m->gathered[(size_t)i].ensure((size_t)n * per)); }
+        if (m->loopback) {
+            // what the all-gather leaves on the root: block r at r * per
+            for (int i = 0; i < n; i++) RRM_HIP(m, hipStreamSynchronize(m->streams[(size_t)i]));
+            for (int i = 0; i < n; i++)
+                RRM_HIP(m, hipMemcpyAsync(m->gathered[0].p + (size_t)i * per, m->block[(size_t)i].p, per, hipMemcpyDeviceToDevice, m->streams[0]));
+        } else {
         RRM_NCCL(m, g_rccl.GroupStart());
         for (int i = 0; i < n; i++)
             RRM_NCCL(m, g_rccl.AllGather(m->block[(size_t)i].p, m->gathered[(size_t)i].p, per, kNcclUint8, m->comms[(size_t)i], m->streams[(size_t)i]));
         RRM_NCCL(m, g_rccl.GroupEnd());
+        }
         d_cols = m->gathered[0].p;                         // [device][n_frames][nl][C]
         n_loc = (int)nl; block_stride = per; frame_stride = nl * C;
     } else {
@@ -271,6 +285,15 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
         RRM_HIP(m, m->gathered[0].ensure((size_t)n_frames * A * C));
         std::vector<size_t> so((size_t)n * n_frames), ro((size_t)n * n_frames), pb((size_t)n * n_frames);
         (void)rr_multi_plan(A, (int)C, n, n_frames, nullptr, nullptr, so.data(), ro.data(), pb.data());
+        if (m->loopback) {
+            for (int i = 0; i < n; i++) RRM_HIP(m, hipStreamSynchronize(m->streams[(size_t)i]));
+            for (int i = 0; i < n; i++)
+                for (int f = 0; f < n_frames; f++) {
+                    const size_t k = (size_t)i * n_frames + f;
+                    if (pb[k] == 0) continue;
+                    RRM_HIP(m, hipMemcpyAsync(m->gathered[0].p + ro[k], m->block[(size_t)i].p + so[k], pb[k], hipMemcpyDeviceToDevice, m->streams[0]));
+                }
+        } else {
         RRM_NCCL(m, g_rccl.GroupStart());
         for (int i = 0; i < n; i++)
             for (int f = 0; f < n_frames; f++) {
@@ -280,6 +303,7 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
                 RRM_NCCL(m, g_rccl.Recv(m->gathered[0].p + ro[k], pb[k], kNcclUint8, i, m->comms[0], m->streams[0]));
             }
         RRM_NCCL(m, g_rccl.GroupEnd());
+        }
         d_cols = m->gathered[0].p;                         // [n_frames][A][C]
     }
     // 3. root: transpose into mono8 images, copy to the caller's host buffer

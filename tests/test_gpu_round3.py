@@ -198,3 +198,29 @@ def test_copy_mesh_replicates_a_finished_tree(native_lib, small):
         got2, _, _ = b.simulate(poses[1])          # a refused copy leaves the tree in place
         assert np.array_equal(got2, ref)
         b.close(); e.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 3, 7, 8])
+def test_multi_loopback_runs_the_n_device_path_on_one_gpu(native_lib, small, monkeypatch, n_dev):
+    """RR_MULTI_LOOPBACK=1: rr_create_multi accepts the same device n times -- n contexts, the map built once and copied
+    (rr_copy_mesh), every context renders its azimuth block of every frame on its own stream, and the ONE collective of
+    the call is replaced by device-to-device copies that follow rr_multi_plan (equal blocks: 2 and 8 devices; ragged:
+    3 and 7).  Everything of the n > 1 path except the RCCL calls themselves: the frames equal rr_simulate's."""
+    s, cfg, mats, beams, noise, poses = small
+    monkeypatch.setenv("RR_MULTI_LOOPBACK", "1")
+    m = native_lib.MultiContext([0] * n_dev)
+    monkeypatch.delenv("RR_MULTI_LOOPBACK")
+    assert m.device_count() == n_dev
+    _setup(m, s, cfg, mats, beams, noise)
+    c = native_lib.Context(0)
+    _setup(c, s, cfg, mats, beams, noise[0])
+    got = m.simulate_batch(poses)
+    for f, p in enumerate(poses):
+        c.set_noise_offsets(noise[f % 4])
+        ref, _, _ = c.simulate(p)
+        assert np.array_equal(got[f], ref), (n_dev, f)
+    c.set_noise_offsets(noise[0])
+    assert np.array_equal(m.simulate(poses[3]), c.simulate(poses[3])[0])      # one frame: noise row 0
+    m.close(); c.close()
+    with pytest.raises(native_lib.RRError, match="listed twice"):      # without the switch the list is refused
+        native_lib.MultiContext([0, 0])
