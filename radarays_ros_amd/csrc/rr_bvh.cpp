@@ -25,6 +25,9 @@
 #include <future>
 #include <limits>
 #include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
 #include <thread>
 
 namespace rr {
@@ -62,6 +65,57 @@ struct Ref {
     uint32_t face;
     uint32_t pad;
 };
+
+// Reference lists are created and dropped at every node: 10M references pass through about twenty levels of them.
+// Straight from malloc that is a page-fault storm (glibc trims the heap and unmaps the freed lists, the next level
+// faults them in again: 9.0 -> 5.7 s for the 10M-triangle map just by telling malloc not to trim), so their blocks
+// come from a pool that lives as long as one build: power-of-two size classes from 64 KB to 64 MB, a free list per
+// class; smaller and larger requests go to malloc.  Elements are default-initialised (a resize does not zero-fill).
+struct BlockPool {
+    static constexpr int kMinShift = 16, kMaxShift = 26, kClasses = kMaxShift - kMinShift + 1;
+    std::mutex mu[kClasses];
+    std::vector<void*> free_[kClasses];
+    static int class_of(size_t bytes) {
+        if (bytes < ((size_t)1 << kMinShift) || bytes > ((size_t)1 << kMaxShift)) return -1;
+        int c = 0;
+        while (((size_t)1 << (kMinShift + c)) < bytes) c++;
+        return c;
+    }
+    void* get(size_t bytes) {
+        const int c = class_of(bytes);
+        if (c < 0) return std::malloc(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu[c]);
+            if (!free_[c].empty()) { void* p = free_[c].back(); free_[c].pop_back(); return p; }
+        }
+        return std::malloc((size_t)1 << (kMinShift + c));
+    }
+    void put(void* p, size_t bytes) {
+        const int c = class_of(bytes);
+        if (c < 0) { std::free(p); return; }
+        std::lock_guard<std::mutex> g(mu[c]);
+        free_[c].push_back(p);
+    }
+    ~BlockPool() { for (auto& f : free_) for (void* p : f) std::free(p); }
+};
+BlockPool* g_pool = nullptr;     // the pool of the build in progress (builds are serialised, see build_bvh4)
+
+template <class T> struct PoolAlloc {
+    using value_type = T;
+    PoolAlloc() = default;
+    template <class U> PoolAlloc(const PoolAlloc<U>&) {}
+    T* allocate(size_t n) {
+        void* p = g_pool ? g_pool->get(n * sizeof(T)) : std::malloc(n * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t n) { if (g_pool) g_pool->put(p, n * sizeof(T)); else std::free(p); }
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }       // default-init: no zero fill
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const PoolAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const PoolAlloc<U>&) const { return false; }
+};
+using RefVec = std::vector<Ref, PoolAlloc<Ref>>;
 
 struct Node2 {
     Box box;
@@ -116,18 +170,47 @@ struct Clipper {
     }
 };
 
+// Node and leaf slots are handed out per THREAD in blocks: one shared counter bumped for every node and every leaf
+// (8M read-modify-writes on two cache lines that 48 threads on two sockets fight over) was what made the 10M-triangle
+// build 14 x slower than the 1M one.  A thread that ends leaves the rest of its blocks unused (holes are harmless:
+// leaves are addressed by {first, count}, nodes by index).
+constexpr uint32_t kNodeBlock = 512;      // nodes (pairs are taken from it)
+constexpr uint64_t kLeafBlock = 4096;     // leaf face slots
+constexpr size_t kMaxAllocThreads = 4096; // upper bound of threads that ever allocate in one build (subtree tasks)
+struct LocalAlloc { uint64_t gen = 0; uint32_t node_next = 0, node_end = 0; uint64_t leaf_next = 0, leaf_end = 0, refs_out = 0, n_spatial = 0; };
+thread_local LocalAlloc tl_alloc;
+std::atomic<uint64_t> g_build_gen{0};
+
 constexpr size_t kChunk = (size_t)1 << 16;   // references per work item of the intra-node loops (fixed: the tree does not depend on the thread count)
 
 struct Builder {
     Clipper clip;
     Node2* nodes; size_t node_cap;
     uint32_t* leaf_faces; size_t leaf_cap;
-    std::atomic<uint32_t> next_node{1};
-    std::atomic<uint64_t> next_leaf{0};
-    std::atomic<int64_t> budget;          // extra references spatial splits may still create
-    std::atomic<int> tasks_left;          // threads that may still be started (subtree tasks and chunk workers)
-    std::atomic<bool> failed{false};
-    std::atomic<uint64_t> n_spatial{0}, n_refs_out{0};
+    // every shared counter on a cache line of its own: `failed`, `budget` and the read-only members above are read at
+    // every node, `tasks_left` is written by every parallel loop
+    alignas(64) std::atomic<uint32_t> next_node{1};
+    alignas(64) std::atomic<uint64_t> next_leaf{0};
+    alignas(64) std::atomic<int64_t> budget;          // extra references spatial splits may still create
+    alignas(64) std::atomic<int> tasks_left;          // threads that may still be started (subtree tasks and chunk workers)
+    alignas(64) std::atomic<bool> failed{false};
+    alignas(64) std::atomic<uint64_t> n_spatial{0};
+    alignas(64) std::atomic<uint64_t> n_refs_out{0};
+    alignas(64) uint64_t gen_pad_ = 0;
+    uint64_t gen = ++g_build_gen;
+    LocalAlloc& local() { if (tl_alloc.gen != gen) { tl_alloc = LocalAlloc(); tl_alloc.gen = gen; } return tl_alloc; }
+    // statistics of this thread -> the builder (at the end of a subtree task / of the root call)
+    void flush_local() { LocalAlloc& l = local(); n_refs_out += l.refs_out; n_spatial += l.n_spatial; l.refs_out = l.n_spatial = 0; }
+    uint64_t alloc_leaf(size_t n) {
+        LocalAlloc& l = local();
+        if (l.leaf_next + n > l.leaf_end) { const uint64_t blk = std::max<uint64_t>(kLeafBlock, n); l.leaf_next = next_leaf.fetch_add(blk); l.leaf_end = l.leaf_next + blk; }
+        const uint64_t f = l.leaf_next; l.leaf_next += n; return f;
+    }
+    uint32_t alloc_node_pair() {
+        LocalAlloc& l = local();
+        if (l.node_next + 2 > l.node_end) { l.node_next = next_node.fetch_add(kNodeBlock); l.node_end = l.node_next + kNodeBlock; }
+        const uint32_t f = l.node_next; l.node_next += 2; return f;
+    }
     float root_area = 0.f, alpha = 1e-5f, beta = 0.f;
     uint32_t max_leaf = kMaxLeafTris;
 
@@ -169,12 +252,12 @@ struct Builder {
     }
     static size_t n_chunks(size_t n) { return std::max<size_t>(1, (n + kChunk - 1) / kChunk); }
 
-    void make_leaf(uint32_t ni, const std::vector<Ref>& refs) {
-        const uint64_t first = next_leaf.fetch_add(refs.size());
+    void make_leaf(uint32_t ni, const RefVec& refs) {
+        const uint64_t first = alloc_leaf(refs.size());
         if (first + refs.size() > leaf_cap) { failed = true; nodes[ni].left = 0; nodes[ni].count = 1; return; }
         for (size_t i = 0; i < refs.size(); i++) leaf_faces[first + i] = refs[i].face;
         nodes[ni].left = (uint32_t)first; nodes[ni].count = (uint32_t)refs.size();
-        n_refs_out += refs.size();
+        local().refs_out += refs.size();
     }
 
     static inline float centroid(const Ref& r, int ax) { return 0.5f * (r.box.lo[ax] + r.box.hi[ax]); }
@@ -186,7 +269,7 @@ struct Builder {
 
     // binned SAH object split over the three axes: ONE pass over the references (chunk-parallel)
     struct ObjBins { Box bb[3][kBins]; uint32_t bc[3][kBins]; };
-    ObjSplit best_object_split(const std::vector<Ref>& refs, const Box& cb) {
+    ObjSplit best_object_split(const RefVec& refs, const Box& cb) {
         float lo[3], scale[3]; bool use[3];
         for (int ax = 0; ax < 3; ax++) {
             const float ext = cb.hi[ax] - cb.lo[ax];
@@ -230,7 +313,7 @@ struct Builder {
 
     // binned spatial split (Stich et al. §4.2): references are chopped into the bins they span; one pass, chunk-parallel
     struct SpaBins { Box bb[3][kBins]; uint32_t en[3][kBins], ex[3][kBins]; };
-    SpaSplit best_spatial_split(const std::vector<Ref>& refs, const Box& nb) {
+    SpaSplit best_spatial_split(const RefVec& refs, const Box& nb) {
         float lo[3], scale[3], width[3]; bool use[3];
         for (int ax = 0; ax < 3; ax++) {
             const float ext = nb.hi[ax] - nb.lo[ax];
@@ -282,8 +365,8 @@ struct Builder {
     }
 
     // per-chunk output of a partition pass, concatenated in chunk order afterwards
-    struct Piece { std::vector<Ref> L, R; Bounds bl, br; int64_t uncut = 0; };
-    void concat(std::vector<Piece>& pc, std::vector<Ref>& L, std::vector<Ref>& R, Bounds& bl, Bounds& br) {
+    struct Piece { RefVec L, R; Bounds bl, br; int64_t uncut = 0; };
+    void concat(std::vector<Piece>& pc, RefVec& L, RefVec& R, Bounds& bl, Bounds& br) {
         std::vector<size_t> ol(pc.size() + 1, 0), orr(pc.size() + 1, 0);
         bl.reset(); br.reset();
         for (size_t c = 0; c < pc.size(); c++) { ol[c + 1] = ol[c] + pc[c].L.size(); orr[c + 1] = orr[c] + pc[c].R.size(); bl.grow(pc[c].bl); br.grow(pc[c].br); }
@@ -292,13 +375,13 @@ struct Builder {
             if (c >= pc.size()) return;
             std::copy(pc[c].L.begin(), pc[c].L.end(), L.begin() + (std::ptrdiff_t)ol[c]);
             std::copy(pc[c].R.begin(), pc[c].R.end(), R.begin() + (std::ptrdiff_t)orr[c]);
-            std::vector<Ref>().swap(pc[c].L); std::vector<Ref>().swap(pc[c].R);
+            RefVec().swap(pc[c].L); RefVec().swap(pc[c].R);
         });
     }
 
-    void recurse(uint32_t left, std::vector<Ref>& L, const Bounds& bl, std::vector<Ref>& R, const Bounds& br, size_t count) {
+    void recurse(uint32_t left, RefVec& L, const Bounds& bl, RefVec& R, const Bounds& br, size_t count) {
         if (count >= kParallelMin && acquire(1) == 1) {
-            auto fut = std::async(std::launch::async, [this, left, &L, &bl] { build(left, L, bl); });
+            auto fut = std::async(std::launch::async, [this, left, &L, &bl] { build(left, L, bl); flush_local(); });
             build(left + 1, R, br);
             fut.get();
             release(1);
@@ -309,11 +392,11 @@ struct Builder {
     }
 
     // consumes `refs`; bd = bounds of the references and of their centroids
-    void build(uint32_t ni, std::vector<Ref>& refs, const Bounds& bd) {
+    void build(uint32_t ni, RefVec& refs, const Bounds& bd) {
         const size_t count = refs.size();
         const Box& nb = bd.nb; const Box& cb = bd.cb;
         nodes[ni].box = nb;
-        if (count <= max_leaf || failed) { make_leaf(ni, refs); std::vector<Ref>().swap(refs); return; }
+        if (count <= max_leaf || failed) { make_leaf(ni, refs); RefVec().swap(refs); return; }
 
         const ObjSplit os = best_object_split(refs, cb);
         bool spatial = false;
@@ -330,7 +413,7 @@ struct Builder {
             }
         }
 
-        std::vector<Ref> L, R;
+        RefVec L, R;
         Bounds bl, br;
         int64_t reserved = 0;
         if (spatial) {
@@ -388,7 +471,7 @@ struct Builder {
             if (L.empty() || R.empty() || L.size() >= count || R.size() >= count) {
                 budget.fetch_add(reserved - uncut);
                 L.clear(); R.clear(); spatial = false;
-            } else n_spatial++;
+            } else local().n_spatial++;
         }
         if (!spatial) {
             bool by_bin = os.axis >= 0;
@@ -418,9 +501,9 @@ struct Builder {
                 for (const Ref& r : R) grow_bounds(br, r);
             }
         }
-        std::vector<Ref>().swap(refs);   // free before descending
+        RefVec().swap(refs);   // free before descending
 
-        const uint32_t left = next_node.fetch_add(2);
+        const uint32_t left = alloc_node_pair();
         if ((size_t)left + 2 > node_cap) { failed = true; nodes[ni].left = 0; nodes[ni].count = 1; return; }
         nodes[ni].left = left; nodes[ni].count = 0;
         recurse(left, L, bl, R, br, count);
@@ -549,6 +632,9 @@ struct Collapser {
 bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
                 const uint32_t* face_object, Bvh4& out, std::string& err, int n_threads, const BvhOptions* opt_in)
 {
+    // one build at a time per process (the SAH weight and the block pool are per-build globals; a build is parallel inside)
+    static std::mutex build_mu;
+    std::lock_guard<std::mutex> build_lock(build_mu);
     const auto t0 = std::chrono::steady_clock::now();
     out = Bvh4();
     BvhOptions opt; if (opt_in) opt = *opt_in;
@@ -576,7 +662,9 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
         return true;
     }
 
-    std::vector<Ref> refs(nf);
+    BlockPool pool;
+    struct PoolScope { PoolScope(BlockPool* p) { g_pool = p; } ~PoolScope() { g_pool = nullptr; } } pool_scope(&pool);
+    RefVec refs(nf);
     Box scene; scene.reset();
     for (size_t f = 0; f < nf; f++) {
         Box b; b.reset();
@@ -596,20 +684,22 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
 
     // more than ~32-64 threads lose to allocator and page-fault contention (10M triangles on a 256-thread host:
     // 36.6 s with 1 thread, 9.7 s with 8, 6.0 s with 32 or 64, 18.8 s with 256)
+    if (n_threads <= 0 && getenv("RR_BVH_THREADS")) n_threads = atoi(getenv("RR_BVH_THREADS"));
     if (n_threads <= 0) n_threads = (int)std::min(48u, std::max(1u, std::thread::hardware_concurrency()));
     const bool verbose = getenv("RR_BVH_VERBOSE") != nullptr;
     auto lap = [&](const char* what) { if (verbose) fprintf(stderr, "[rr bvh] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); };
     lap("validated, references made");
     const double budget_f = std::max(0.0, (double)opt.ref_budget) * (double)nf;
     const size_t max_refs = std::min<size_t>(nf + (size_t)budget_f + 16, (size_t)1 << 28);
-    const size_t node_cap = 2 * max_refs + 1;
+    const size_t node_cap = 2 * max_refs + 1 + kMaxAllocThreads * kNodeBlock;      // untouched pages cost nothing
+    const size_t leaf_cap = max_refs + kMaxAllocThreads * kLeafBlock;
     std::unique_ptr<Node2[]> n2(new Node2[node_cap]);                 // default-initialised: pages are touched on use only
-    std::unique_ptr<uint32_t[]> leaf_faces(new uint32_t[max_refs]);
+    std::unique_ptr<uint32_t[]> leaf_faces(new uint32_t[leaf_cap]);
     uint64_t n_leaf_refs = 0; uint32_t n_nodes_used = 1;
     {
         Builder b{ Clipper{ verts, faces } };
         b.nodes = n2.get(); b.node_cap = node_cap;
-        b.leaf_faces = leaf_faces.get(); b.leaf_cap = max_refs;
+        b.leaf_faces = leaf_faces.get(); b.leaf_cap = leaf_cap;
         b.budget = (int64_t)(max_refs - nf - 16 > 0 ? max_refs - nf - 16 : 0);
         b.tasks_left = n_threads - 1;
         b.root_area = scene.half_area(); b.alpha = opt.sbvh_alpha; b.beta = opt.sbvh_beta;
@@ -617,8 +707,9 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
         Builder::Bounds bd; bd.reset();
         for (const Ref& r : refs) Builder::grow_bounds(bd, r);
         b.build(0, refs, bd);
+        b.flush_local();
         if (b.failed) { err = "rr_set_mesh: internal error (reference budget exceeded)"; return false; }
-        n_leaf_refs = b.next_leaf.load();
+        n_leaf_refs = b.n_refs_out.load();
         n_nodes_used = b.next_node.load();
         out.spatial_splits = b.n_spatial.load();
     }

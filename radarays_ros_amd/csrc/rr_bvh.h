@@ -65,7 +65,7 @@ struct BvhOptions {
     // sbvh_alpha x the root's surface area; < 0 switches them off (plain binned SAH)
     float sbvh_alpha = 1e-5f;
     // ... and by more than sbvh_beta x the node's own surface area (see rr_bvh.cpp)
-    float sbvh_beta = 0.0f;
+    float sbvh_beta = 0.05f;
     // weight of the horizontal (xy) face of a box in the SAH's area: 1 = isotropic rays (the textbook SAH); < 1 says the
     // rays are mostly horizontal, as a radar's are (map z up; +-5 degrees of beam, reflections off walls stay level):
     // a box is then hit in proportion to its vertical cross-sections, and growing a node upwards is what costs.
