@@ -176,7 +176,6 @@ struct Clipper {
 // leaves are addressed by {first, count}, nodes by index).
 constexpr uint32_t kNodeBlock = 512;      // nodes (pairs are taken from it)
 constexpr uint64_t kLeafBlock = 4096;     // leaf face slots
-constexpr size_t kMaxAllocThreads = 4096; // upper bound of threads that ever allocate in one build (subtree tasks)
 struct LocalAlloc { uint64_t gen = 0; uint32_t node_next = 0, node_end = 0; uint64_t leaf_next = 0, leaf_end = 0, refs_out = 0, n_spatial = 0; };
 thread_local LocalAlloc tl_alloc;
 std::atomic<uint64_t> g_build_gen{0};
@@ -691,8 +690,11 @@ bool build_bvh4(const float* verts, size_t nv, const uint32_t* faces, size_t nf,
     lap("validated, references made");
     const double budget_f = std::max(0.0, (double)opt.ref_budget) * (double)nf;
     const size_t max_refs = std::min<size_t>(nf + (size_t)budget_f + 16, (size_t)1 << 28);
-    const size_t node_cap = 2 * max_refs + 1 + kMaxAllocThreads * kNodeBlock;      // untouched pages cost nothing
-    const size_t leaf_cap = max_refs + kMaxAllocThreads * kLeafBlock;
+    // every thread that allocates (the caller + one per subtree task: a task is started for nodes of >= kParallelMin
+    // references only) may leave one block of each kind unused; untouched pages cost nothing
+    const size_t alloc_threads = 2 * max_refs / kParallelMin + 64;
+    const size_t node_cap = 2 * max_refs + 1 + alloc_threads * kNodeBlock;
+    const size_t leaf_cap = max_refs + alloc_threads * kLeafBlock;
     std::unique_ptr<Node2[]> n2(new Node2[node_cap]);                 // default-initialised: pages are touched on use only
     std::unique_ptr<uint32_t[]> leaf_faces(new uint32_t[leaf_cap]);
     uint64_t n_leaf_refs = 0; uint32_t n_nodes_used = 1;
