@@ -103,14 +103,15 @@ public:
     // One backend object per process like the reference (radar_simulator.cpp:145-176); `devices` lists the GPUs
     // of this node it fans out over (rr_multi: azimuth blocks, one RCCL collective per frame).
     RadarHIP(std::string map_frame, std::string sensor_frame, const std::vector<float>& verts,
-             const std::vector<uint32_t>& faces, const std::vector<uint32_t>& face_object, const std::vector<int>& devices)
+             const std::vector<uint32_t>& faces, const std::vector<uint32_t>& face_object, const std::vector<int>& devices,
+             bool build_on_gpu = false /* rr_set_mesh_gpu: the map loads in 0.35 s instead of 3.9 s at 10M triangles, frames take 1.2x as long */)
     : Radar(std::move(map_frame), std::move(sensor_frame))
     {
         m_multi = rr_create_multi(devices.data(), (int)devices.size());
         if (!m_multi) throw std::runtime_error(rr_multi_last_error(nullptr));
         m_ctx = rr_multi_ctx(m_multi, 0);
-        if (rr_multi_set_mesh(m_multi, verts.data(), verts.size() / 3, faces.data(), faces.size() / 3,
-                              face_object.empty() ? nullptr : face_object.data())) {
+        if ((build_on_gpu ? rr_multi_set_mesh_gpu : rr_multi_set_mesh)(m_multi, verts.data(), verts.size() / 3, faces.data(), faces.size() / 3,
+                                                                        face_object.empty() ? nullptr : face_object.data())) {
             std::string e = rr_multi_last_error(m_multi); rr_destroy_multi(m_multi); throw std::runtime_error(e);
         }
     }

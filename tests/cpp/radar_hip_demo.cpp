@@ -56,7 +56,7 @@ int main(int argc, char** argv)
         }
         // the same backend constructed over a device LIST (rr_multi; one device here): identical bytes
         {
-            RadarHIP multi("map", "navtech", verts, faces, fobj, std::vector<int>{ 0 });
+            RadarHIP multi("map", "navtech", verts, faces, fobj, std::vector<int>{ 0 }, /*build_on_gpu=*/true);   // the tree does not change an image
             multi.loadParams(m, std::vector<int>(objmat.begin(), objmat.end()), 0);
             multi.updateDynCfg(cfg); multi.setBeamSamples(beams); multi.updateTsm(pose.data());
             ImagePtr img2 = multi.simulate(42.5);
