@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <random>
+#include <string>
 #include <vector>
 
 using namespace rr;
@@ -87,9 +88,28 @@ static int check(const std::vector<float>& v, const std::vector<uint32_t>& f, in
     return 0;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     int bad = 0;
+    if (argc > 1 && std::string(argv[1]) == "big") {
+        // large enough for everything that runs in parallel: subtree tasks (>= 32k references), chunk-parallel binning and
+        // partition (>= 64k), the block pool and the per-thread slot blocks -- the case the ThreadSanitizer test runs.
+        // Two builds: the per-thread state of the calling thread must start afresh
+        std::vector<float> v; std::vector<uint32_t> f;
+        auto tri = [&](float x, float y, float z, float s, float tilt) {
+            const uint32_t b0 = (uint32_t)(v.size() / 3);
+            const float p[9] = { x, y, z, x + s, y, z + tilt * s, x, y + s, z + 0.5f * tilt * s };
+            v.insert(v.end(), p, p + 9);
+            f.push_back(b0); f.push_back(b0 + 1); f.push_back(b0 + 2);
+        };
+        std::mt19937 g(11);
+        std::uniform_real_distribution<float> U(0.f, 1.f);
+        for (int i = 0; i < 400; i++) for (int j = 0; j < 400; j++) tri(0.25f * i, 0.25f * j, 0.02f * ((i * 7 + j * 13) % 11), 0.25f, 0.1f);
+        for (int k = 0; k < 2000; k++) tri(100.f * U(g), 100.f * U(g), 0.01f * k, 4.f + 10.f * U(g), (k % 5) * 0.3f);
+        bad += check(v, f, 8, "big mixed-scales", true);
+        bad += check(v, f, 8, "big mixed-scales again", true);
+        return bad ? 1 : 0;
+    }
     std::mt19937 g(7);
     std::uniform_real_distribution<float> U(-20.f, 20.f), S(-0.5f, 0.5f);
     for (int n : { 1, 2, 3, 4, 5, 17, 1000, 20000 }) {
