@@ -111,7 +111,7 @@ int rr_set_mesh(rr_ctx* ctx, const float* verts /*[nv][3]*/, size_t nv,
                 const uint32_t* face_object_id /*[nf] or NULL*/);
 
 /* Same contract, but the BVH is built ON THE GPU (early split clipping of oversized faces + Morton codes + rocprim
- * radix sort + Karras radix tree + refit + 4-wide collapse): 0.35 s instead of 3.9 s for 10M triangles, tree of
+ * radix sort + Karras radix tree + refit + 4-wide collapse): 0.35 s instead of 1.9 s for 10M triangles, tree of
  * lower quality (rays traverse about 1.2x slower than through the host builder's SAH tree with spatial splits).
  * Images are bit-identical whichever builder made the tree: the nearest hit is defined independently of
  * traversal order. */

@@ -104,7 +104,7 @@ public:
     // of this node it fans out over (rr_multi: azimuth blocks, one RCCL collective per frame).
     RadarHIP(std::string map_frame, std::string sensor_frame, const std::vector<float>& verts,
              const std::vector<uint32_t>& faces, const std::vector<uint32_t>& face_object, const std::vector<int>& devices,
-             bool build_on_gpu = false /* rr_set_mesh_gpu: the map loads in 0.35 s instead of 3.9 s at 10M triangles, frames take 1.2x as long */)
+             bool build_on_gpu = false /* rr_set_mesh_gpu: the map loads in 0.35 s instead of 1.9 s at 10M triangles, frames take 1.2x as long */)
     : Radar(std::move(map_frame), std::move(sensor_frame))
     {
         m_multi = rr_create_multi(devices.data(), (int)devices.size());

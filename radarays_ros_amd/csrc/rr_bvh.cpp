@@ -131,6 +131,52 @@ constexpr uint32_t kParallelMin = 1u << 15;
 struct Clipper {
     const float* verts; const uint32_t* faces;
 
+    // The boxes of (triangle `f`) in the consecutive slabs [lo + b w, lo + (b + 1) w], b = b0..b1 of one axis, for the
+    // EVALUATION of a spatial split (the first and last slab are open outwards).  One sweep: every inner slab boundary
+    // cuts the triangle in a segment (two edge interpolations), a slab's part is bounded by the segments of its two
+    // boundaries and the vertices between them.  About 4x cheaper than clipping the triangle against every slab anew;
+    // no outward rounding (the cut itself, slab() below, is what has to cover the face).
+    void slab_boxes(uint32_t f, int axis, float lo, float width, int b0, int b1, Box* out /* [b1 - b0 + 1] */) const {
+        double v[3][3];
+        for (int k = 0; k < 3; k++) {
+            const float* a = verts + 3 * (size_t)faces[3 * (size_t)f + k];
+            v[k][0] = a[0]; v[k][1] = a[1]; v[k][2] = a[2];
+        }
+        int ia = 0, ib = 1, ic = 2;          // vertices in ascending order along the axis
+        if (v[ia][axis] > v[ib][axis]) std::swap(ia, ib);
+        if (v[ib][axis] > v[ic][axis]) std::swap(ib, ic);
+        if (v[ia][axis] > v[ib][axis]) std::swap(ia, ib);
+        const double* A = v[ia]; const double* Bv = v[ib]; const double* C = v[ic];
+        auto cut = [&](const double* u, const double* w, double plane, double* q) {
+            const double t = (plane - u[axis]) / (w[axis] - u[axis]);
+            for (int k = 0; k < 3; k++) q[k] = u[k] + t * (w[k] - u[k]);
+            q[axis] = plane;
+        };
+        auto grow = [](Box& bx, const double* q) {
+            for (int k = 0; k < 3; k++) { bx.lo[k] = std::min(bx.lo[k], (float)q[k]); bx.hi[k] = std::max(bx.hi[k], (float)q[k]); }
+        };
+        const int n = b1 - b0 + 1;
+        for (int i = 0; i < n; i++) out[i].reset();
+        // vertices into their slabs
+        for (int k = 0; k < 3; k++) {
+            int b = (int)std::floor((v[k][axis] - (double)lo) / (double)width);
+            b = std::min(std::max(b, b0), b1);
+            grow(out[b - b0], v[k]);
+        }
+        // inner boundaries: plane b separates slab b - 1 from slab b
+        for (int b = b0 + 1; b <= b1; b++) {
+            const double plane = (double)lo + (double)b * (double)width;
+            if (!(plane > A[axis] && plane < C[axis])) continue;
+            double q1[3], q2[3];
+            cut(A, C, plane, q1);
+            if (plane < Bv[axis]) cut(A, Bv, plane, q2);
+            else if (plane > Bv[axis]) cut(Bv, C, plane, q2);
+            else { q2[0] = Bv[0]; q2[1] = Bv[1]; q2[2] = Bv[2]; }
+            grow(out[b - 1 - b0], q1); grow(out[b - 1 - b0], q2);
+            grow(out[b - b0], q1); grow(out[b - b0], q2);
+        }
+    }
+
     Box slab(uint32_t f, int axis, float lo, float hi) const {
         double p[8][3], q[8][3];
         int n = 3;
@@ -330,10 +376,10 @@ struct Builder {
                     b0 = std::min(std::max(b0, 0), kBins - 1); b1 = std::min(std::max(b1, b0), kBins - 1);
                     B.en[ax][b0]++; B.ex[ax][b1]++;
                     if (b0 == b1) { B.bb[ax][b0].grow(r.box); continue; }
+                    Box parts[kBins];
+                    clip.slab_boxes(r.face, ax, lo[ax], width[ax], b0, b1, parts);
                     for (int b = b0; b <= b1; b++) {
-                        const float plo = b == b0 ? -std::numeric_limits<float>::infinity() : lo[ax] + (float)b * width[ax];
-                        const float phi = b == b1 ? std::numeric_limits<float>::infinity() : lo[ax] + (float)(b + 1) * width[ax];
-                        Box cbx = clip.slab(r.face, ax, plo, phi);
+                        Box& cbx = parts[b - b0];
                         cbx.clip_to(r.box);
                         if (cbx.valid()) B.bb[ax][b].grow(cbx);
                     }

@@ -158,7 +158,7 @@ rr_ctx* rr_multi_ctx(rr_multi* m, int i) { return (m && i >= 0 && (size_t)i < m-
 int rr_multi_set_mesh(rr_multi* m, const float* verts, size_t nv, const uint32_t* faces, size_t nf, const uint32_t* face_object_id)
 {
     if (!m) return -1;
-    // ONE build (3.9 s of host time at 10M triangles), then the finished tree goes from device to device (xGMI)
+    // ONE build (1.9 s of host time at 10M triangles), then the finished tree goes from device to device (xGMI)
     { rr_ctx* c = m->ctx[0]; const int rc = rr_set_mesh(c, verts, nv, faces, nf, face_object_id);
       if (rc) return mfail(m, rc, std::string("device ") + std::to_string(m->devices[0]) + ": " + rr_last_error(c)); }
     for (size_t i = 1; i < m->ctx.size(); i++) {
