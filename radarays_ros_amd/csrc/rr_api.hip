@@ -156,7 +156,7 @@ struct rr_ctx {
     bool roctx = false;
     int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
     int cull_pop = 1;            // k_trace's later passes drop stack entries at pop time (RR_CULL_POP=0: off; the images are the same either way)
-    int copy_blocks = 4;         // workgroups (2 waves each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
+    int copy_blocks = 8;         // workgroups (one wave each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
 };
 
 namespace {
@@ -390,7 +390,7 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     // one spill column per ray slot a launch can address: later passes ceil(cap/32)*32 slots per segment,
     // pass 0 its (sample x azimuth) tiles, whose padding can exceed S * n_beam (e.g. ONE segment: 16 x n_beam)
     const size_t A0 = (size_t)c->pass0_az, Sw0 = 16 / A0;
-    const size_t slots0 = ((((S + A0 - 1) / A0) * (((size_t)n_beam + Sw0 - 1) / Sw0) + 1) / 2) * 32;
+    const size_t slots0 = ((((S + A0 - 1) / A0) * (((size_t)n_beam + Sw0 - 1) / Sw0) + 1) / 2) * 32;      // (rounded up to pairs of waves: covers 64- and 128-thread workgroups)
     const size_t threads = std::max(S * (size_t)((cap + 63) / 64) * 64, slots0);
     L.spill_stride = (int)threads;
     if (spill_depth > 0) RR_HIP(c, L.d_spill.ensure((size_t)spill_depth * threads));
@@ -642,7 +642,7 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_ROCTX") && atoi(getenv("RR_ROCTX")) != 0) c->roctx = roctx_load();
     if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
     if (getenv("RR_CULL_POP")) c->cull_pop = atoi(getenv("RR_CULL_POP")) != 0;
-    if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(13, atoi(getenv("RR_COPY_BLOCKS"))));
+    if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||

@@ -56,7 +56,7 @@ struct Hit { float t; uint32_t tri; uint32_t face; };
 // quad) and spills to global memory beyond `stack_lds` entries.
 // ---------------------------------------------------------------------------
 constexpr int kRaysPerWave = 16;
-constexpr int kTraceThreads = 128;                       // 32 rays per workgroup (measured: 64/128 threads beat 256/512 -- a workgroup holds its LDS until its slowest wave is done)
+constexpr int kTraceThreads = 64;                        // ONE wave = 16 rays per workgroup: a wave gives its LDS and its slot back the moment it is done, no barrier waits for a sibling (128 threads: 461 vs 447 us per later-pass launch alone, 4,170-4,190 vs 4,270-4,290 images/s on the target; 256 / 512 lose more)
 constexpr int kRaysPerBlock = kTraceThreads / 4;
 #ifndef RR_CULL_POP
 #define RR_CULL_POP 1
@@ -1163,7 +1163,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     // launched beyond that bound (pass 1 of the KAIST preset: 13 instead of 50 blocks per segment; the rest would
     // read their segment's count and exit)
     const long bound = std::min<long>((long)P.cap, pass < 20 ? (long)P.n_beam << pass : (long)P.cap);
-    dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + 1) / 2))
+    dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + (kTraceThreads / 64) - 1) / (kTraceThreads / 64)))
                           : dim3((unsigned)((bound + kRaysPerBlock - 1) / kRaysPerBlock), n_seg + (P.copy_blocks > 0 ? 1 : 0));
     Params Pl = P;
     if (pass == 0) Pl.copy_blocks = 0;
@@ -1172,7 +1172,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     // later passes cull stack entries at pop time (6-B entries) as long as 16 workgroups still fit a CU's 160 KB of LDS
     // (10 KB each: up to 53 entries); a deeper tree keeps the 4-B entries -- the lost occupancy would cost more than the
     // cull returns (GPU-built tree of the 10M-triangle target, 56 entries: 0.465 vs 0.442 ms per frame)
-    const bool cull = kCullPop && P.cull_pop && pass > 0 && (size_t)P.stack_lds * kRaysPerBlock * 6 <= 10240;
+    const bool cull = kCullPop && P.cull_pop && pass > 0 && (size_t)P.stack_lds * kRaysPerBlock * 6 <= 10240 / (128 / kTraceThreads);
     const size_t lds = std::max((size_t)P.stack_lds * kRaysPerBlock * (cull ? 6 : 4), kHandoffBytes);
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
