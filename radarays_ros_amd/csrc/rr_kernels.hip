@@ -62,7 +62,6 @@ constexpr int kRaysPerBlock = kTraceThreads / 4;
 #define RR_CULL_POP 1
 #endif
 constexpr bool kCullPop = RR_CULL_POP != 0;   // later passes: stack entries carry a 16-bit lower bound of their entry distance (6 B per entry)
-constexpr size_t kHandoffBytes = 14 * kRaysPerBlock * 4;    // k_trace: 12 floats + 2 ints per ray, aliased with the stack
 
 #define RR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true)
 #define RR_DPP_F(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xF, 0xF, true))
@@ -242,12 +241,6 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     // column / shade waves of the other steps in flight (config 2: live launch 135 -> 122 us)
     __builtin_amdgcn_s_setprio(2);
     extern __shared__ uint32_t lds_stack[];
-    // prepared rays of the workgroup, one per lane of wave 0 (a quad would otherwise repeat the
-    // pose algebra four times and every wave would issue it for just 16 rays).  They are read once, before the
-    // traversal starts: the hand-off area is the bottom of the stack area (kHandoffBytes <= the launch's dynamic LDS)
-    float (*s_ray)[kRaysPerBlock] = reinterpret_cast<float (*)[kRaysPerBlock]>(lds_stack);
-    int* s_j = reinterpret_cast<int*>(lds_stack + 12 * kRaysPerBlock);
-    int* s_seg = s_j + kRaysPerBlock;
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int cur = pass & 1;
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
@@ -277,10 +270,11 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     const int seg_y = (int)blockIdx.y - row0;
     const int count = FIRST ? 0 : (int)P.count[cur][seg_y];
     if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
-    if (threadIdx.x < kRaysPerBlock) {
-        const int rr = threadIdx.x;
+    RaySetup R; int j, seg;
+    {
+        const int rr = r;          // every lane of the quad prepares its ray itself: the same instructions as one lane per ray and an LDS hand-off (round 2), without the hand-off and its two barriers
         int k = blockIdx.x * kRaysPerBlock + rr;           // trace slot
-        int seg = seg_y;
+        seg = seg_y;
         bool live = k < count;
         if (FIRST) {
             // wave w = tile (sample block sb, azimuth block ab) of (16 / A) samples x A neighbouring segments
@@ -295,7 +289,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         }
         // pass 0 is traced in a sorted order of the beam samples (rows of equal elevation); results are
         // stored under the wave's own index j, so the reference order is untouched
-        int j = -1;
+        j = -1;
         V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
         if (live) {
             j = FIRST ? (int)P.beam_order[k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
@@ -312,25 +306,12 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         }
         Quat q_am; V3 t_am;
         azimuth_frame(P, seg, q_am, t_am);
-        const RaySetup R = ray_setup(v_add(q_rot(q_am, orig), t_am), q_rot(q_am, dir));
-        s_ray[0][rr] = R.o.x; s_ray[1][rr] = R.o.y; s_ray[2][rr] = R.o.z;
-        s_ray[3][rr] = R.d.x; s_ray[4][rr] = R.d.y; s_ray[5][rr] = R.d.z;
-        s_ray[6][rr] = R.idx; s_ray[7][rr] = R.idy; s_ray[8][rr] = R.idz;
-        s_ray[9][rr] = R.oox; s_ray[10][rr] = R.ooy; s_ray[11][rr] = R.ooz;
-        s_j[rr] = j; s_seg[rr] = seg;
+        R = ray_setup(v_add(q_rot(q_am, orig), t_am), q_rot(q_am, dir));
     }
-    __syncthreads();
-    const int j = s_j[r];
-    const int seg = s_seg[r];
     const bool active = j >= 0;
 
     unsigned nn = 0, nt = 0;
     unsigned ws[4] = { 0, 0, 0, 0 };
-    RaySetup R;
-    R.o = { s_ray[0][r], s_ray[1][r], s_ray[2][r] }; R.d = { s_ray[3][r], s_ray[4][r], s_ray[5][r] };
-    R.idx = s_ray[6][r]; R.idy = s_ray[7][r]; R.idz = s_ray[8][r];
-    R.oox = s_ray[9][r]; R.ooy = s_ray[10][r]; R.ooz = s_ray[11][r];
-    __syncthreads();      // every ray has left the hand-off area: it is stack from here on
     if (active) {
         const int gray = ((FIRST ? 0 : seg_y) * (int)gridDim.x + (int)blockIdx.x) * kRaysPerBlock + r;   // spill column of this ray slot
         const Hit h = traverse<STATS, SPILL, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
@@ -1173,7 +1154,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     // (10 KB each: up to 53 entries); a deeper tree keeps the 4-B entries -- the lost occupancy would cost more than the
     // cull returns (GPU-built tree of the 10M-triangle target, 56 entries: 0.465 vs 0.442 ms per frame)
     const bool cull = kCullPop && P.cull_pop && pass > 0 && (size_t)P.stack_lds * kRaysPerBlock * 6 <= 10240 / (128 / kTraceThreads);
-    const size_t lds = std::max((size_t)P.stack_lds * kRaysPerBlock * (cull ? 6 : 4), kHandoffBytes);
+    const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * (cull ? 6 : 4);
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
     // rocprofv3 reports), not the time the launch spent waiting for CUs held by other streams
