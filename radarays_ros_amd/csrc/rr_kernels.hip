@@ -794,7 +794,7 @@ void launch_decay_table(float* decay, int n_cells, double resolution, double ene
 // so the column is bit-reproducible and equal to the sequential CPU loop.
 // ---------------------------------------------------------------------------
 constexpr int kSigChunk = 2048;
-constexpr int kColThreads = 512;
+constexpr int kColThreads = 256;   // 4 waves per azimuth column (measured: 512 -0.5..1 %, 1024 -12..26 %)
 constexpr int kColWaves = kColThreads / 64;
 
 __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
