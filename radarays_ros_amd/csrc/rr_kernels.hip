@@ -626,52 +626,73 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
     const int cur = pass & 1, nxt = cur ^ 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
     const int n_slots = 2 * count;
-    const bool last = false;   // the last pass is consumed directly by k_column
     const size_t base2 = (size_t)seg * 2 * P.cap;
 
     int n_child = 0;
     int n_sig = FIRST ? 0 : (int)P.sig_count[seg];
     const int sig_before = n_sig;
-    int n_hit = 0;
+    int n_hit = 0, n_refl = 0, my_hits = 0;
     unsigned ovf = 0;
     for (int b = 0; b < n_slots; b += 256) {
         const int s = b + threadIdx.x;
         uint8_t f = 0; SigRec sr = { -1, 0.0f };
         if (s < n_slots) { f = P.cflag[base2 + s]; sr = P.sigtmp[base2 + s]; }
         const int hit = (f >> 2) & 1;
-        int tot;
-        if (!last) {
-            const int c = f & 1;
-            const int pos = n_child + block_excl_scan(c, tot, lds);
-            if (c) { if (pos < P.cap) { P.idx[nxt][(size_t)seg * P.cap + pos] = (uint32_t)s; P.refpos[base2 + s] = (uint32_t)pos; } else { ovf = 1; P.refpos[base2 + s] = 0xFFFFFFFFu; } }
-            n_child += tot;
-        }
+        // the counts of a 256-slot block ride in ONE scan, 10 bits apart: children (even slots = reflections and odd slots
+        // = refractions apart: the trace order below needs the number of reflections), signals; hits are only summed
+        const int c = f & 1;
         const int g = sr.cell >= 0 ? 1 : 0;
-        const int spos = n_sig + block_excl_scan(g, tot, lds);
+        int tot;
+        const int pre = block_excl_scan(((s & 1) ? (c << 10) : c) | (g << 20), tot, lds);
+        const int pos = n_child + (pre & 1023) + ((pre >> 10) & 1023);
+        if (c) { if (pos < P.cap) { P.idx[nxt][(size_t)seg * P.cap + pos] = (uint32_t)s; P.refpos[base2 + s] = (uint32_t)pos; } else { ovf = 1; P.refpos[base2 + s] = 0xFFFFFFFFu; } }
+        n_child += (tot & 1023) + ((tot >> 10) & 1023);
+        n_refl += tot & 1023;
+        const int spos = n_sig + ((pre >> 20) & 1023);
         if (g) { if (spos < P.sigcap) P.sig[(size_t)seg * P.sigcap + spos] = sr; else ovf = 1; }
-        n_sig += tot;
-        block_excl_scan(hit, tot, lds);
-        n_hit += tot;
+        n_sig += (tot >> 20) & 1023;
+        my_hits += hit;
+    }
+    {   // hits of the pass: one reduction instead of a scan per block
+        int tot;
+        block_excl_scan(my_hits, tot, lds);
+        n_hit = tot;
     }
     // trace order of the next pass: children in the (spatially sorted) trace order of their
     // parents, all reflections first, then all refractions -> neighbouring quads stay coherent
     __syncthreads();
     {
-        int placed = 0;
-        for (int type = 0; type < 2; type++) {
-            for (int b = 0; b < count; b += 256) {
-                const int k = b + threadIdx.x;
-                int c = 0; uint32_t rp = 0xFFFFFFFFu;
-                if (k < count) {
-                    const uint32_t j = FIRST ? P.beam_order2[k] : P.torder[cur][(size_t)seg * P.cap + k];
-                    const size_t sl = base2 + 2 * (size_t)j + type;
-                    if (P.cflag[sl] & 1) { rp = P.refpos[sl]; c = rp != 0xFFFFFFFFu; }
+        // both children of a parent in one sweep: reflections fill [0, R), refractions [R, ...), R = the number of PLACED
+        // reflections (a child beyond the capacity has no reference position and no place in the trace order)
+        int n_refl_placed = 0;
+        {
+            // reflections sit at even slots; the ordered list holds slots in increasing order, so the placed ones are a
+            // prefix: count those among the first min(n_child, cap) entries = reflections whose position is below cap
+            n_refl_placed = n_refl;
+            if (n_child > P.cap) {       // overflow (reported): recount exactly
+                int mine = 0;
+                for (int k = threadIdx.x; k < count; k += 256) {
+                    const size_t sl = base2 + 2 * (size_t)k;
+                    if ((P.cflag[sl] & 1) && P.refpos[sl] != 0xFFFFFFFFu) mine++;
                 }
-                int tot;
-                const int pos = placed + block_excl_scan(c, tot, lds);
-                if (c) P.torder[nxt][(size_t)seg * P.cap + pos] = rp;
-                placed += tot;
+                int tot; block_excl_scan(mine, tot, lds); n_refl_placed = tot;
             }
+        }
+        int placed0 = 0, placed1 = 0;
+        for (int b = 0; b < count; b += 256) {
+            const int k = b + threadIdx.x;
+            int c0 = 0, c1 = 0; uint32_t rp0 = 0xFFFFFFFFu, rp1 = 0xFFFFFFFFu;
+            if (k < count) {
+                const uint32_t j = FIRST ? P.beam_order2[k] : P.torder[cur][(size_t)seg * P.cap + k];
+                const size_t sl = base2 + 2 * (size_t)j;
+                if (P.cflag[sl] & 1) { rp0 = P.refpos[sl]; c0 = rp0 != 0xFFFFFFFFu; }
+                if (P.cflag[sl + 1] & 1) { rp1 = P.refpos[sl + 1]; c1 = rp1 != 0xFFFFFFFFu; }
+            }
+            int tot;
+            const int pre = block_excl_scan(c0 | (c1 << 10), tot, lds);
+            if (c0) P.torder[nxt][(size_t)seg * P.cap + placed0 + (pre & 1023)] = rp0;
+            if (c1) P.torder[nxt][(size_t)seg * P.cap + n_refl_placed + placed1 + ((pre >> 10) & 1023)] = rp1;
+            placed0 += tot & 1023; placed1 += (tot >> 10) & 1023;
         }
     }
     if (__syncthreads_or((int)ovf) && threadIdx.x == 0) { atomicOr(&P.counters->overflow, 1u); atomicOr(P.sticky, 1u); }
