@@ -633,10 +633,14 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
     const int sig_before = n_sig;
     int n_hit = 0, n_refl = 0, my_hits = 0;
     unsigned ovf = 0;
+    // the loads of block b + 1 are in flight while block b is scanned (a block is two barriers and a dependent scatter)
+    uint8_t f_nx = 0; SigRec sr_nx = { -1, 0.0f };
+    if ((int)threadIdx.x < n_slots) { f_nx = P.cflag[base2 + threadIdx.x]; sr_nx = P.sigtmp[base2 + threadIdx.x]; }
     for (int b = 0; b < n_slots; b += 256) {
         const int s = b + threadIdx.x;
-        uint8_t f = 0; SigRec sr = { -1, 0.0f };
-        if (s < n_slots) { f = P.cflag[base2 + s]; sr = P.sigtmp[base2 + s]; }
+        const uint8_t f = f_nx; const SigRec sr = sr_nx;
+        f_nx = 0; sr_nx = { -1, 0.0f };
+        if (s + 256 < n_slots) { f_nx = P.cflag[base2 + s + 256]; sr_nx = P.sigtmp[base2 + s + 256]; }
         const int hit = (f >> 2) & 1;
         // the counts of a 256-slot block ride in ONE scan, 10 bits apart: children (even slots = reflections and odd slots
         // = refractions apart: the trace order below needs the number of reflections), signals; hits are only summed
@@ -679,15 +683,22 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
             }
         }
         int placed0 = 0, placed1 = 0;
-        for (int b = 0; b < count; b += 256) {
-            const int k = b + threadIdx.x;
-            int c0 = 0, c1 = 0; uint32_t rp0 = 0xFFFFFFFFu, rp1 = 0xFFFFFFFFu;
+        auto fetch = [&](int k, int& c0, int& c1, uint32_t& rp0, uint32_t& rp1) {
+            c0 = c1 = 0; rp0 = rp1 = 0xFFFFFFFFu;
             if (k < count) {
                 const uint32_t j = FIRST ? P.beam_order2[k] : P.torder[cur][(size_t)seg * P.cap + k];
                 const size_t sl = base2 + 2 * (size_t)j;
-                if (P.cflag[sl] & 1) { rp0 = P.refpos[sl]; c0 = rp0 != 0xFFFFFFFFu; }
-                if (P.cflag[sl + 1] & 1) { rp1 = P.refpos[sl + 1]; c1 = rp1 != 0xFFFFFFFFu; }
+                const uint2 rp = *reinterpret_cast<const uint2*>(P.refpos + sl);      // both children: one 8-B load (sl is even)
+                const uint8_t f0 = P.cflag[sl], f1 = P.cflag[sl + 1];
+                if (f0 & 1) { rp0 = rp.x; c0 = rp0 != 0xFFFFFFFFu; }
+                if (f1 & 1) { rp1 = rp.y; c1 = rp1 != 0xFFFFFFFFu; }
             }
+        };
+        int c0n, c1n; uint32_t rp0n, rp1n;
+        fetch((int)threadIdx.x, c0n, c1n, rp0n, rp1n);
+        for (int b = 0; b < count; b += 256) {
+            const int c0 = c0n, c1 = c1n; const uint32_t rp0 = rp0n, rp1 = rp1n;
+            fetch(b + 256 + (int)threadIdx.x, c0n, c1n, rp0n, rp1n);
             int tot;
             const int pre = block_excl_scan(c0 | (c1 << 10), tot, lds);
             if (c0) P.torder[nxt][(size_t)seg * P.cap + placed0 + (pre & 1023)] = rp0;
