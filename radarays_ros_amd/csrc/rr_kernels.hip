@@ -233,7 +233,7 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
     return best;
 }
 
-// grid: (ceil(cap/32), n_seg), block 128 (= 32 rays), dynamic LDS = 2 waves * stack_lds * 16 * 4
+// grid: (ceil(bound/16) [+ a copy row], n_seg), block 64 (= one wave = 16 rays), dynamic LDS = stack_lds * 16 * (4 | 6) B
 template <bool FIRST, bool STATS, bool SPILL, bool CULL>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
 {
@@ -1182,8 +1182,8 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     if (pass == 0) Pl.copy_blocks = 0;
     else Pl.copy_blocks = std::min<int>(P.copy_blocks, (int)grid.x);      // the copy's workgroups are the first of row 0
     dim3 block(kTraceThreads);
-    // later passes cull stack entries at pop time (6-B entries) as long as 16 workgroups still fit a CU's 160 KB of LDS
-    // (10 KB each: up to 53 entries); a deeper tree keeps the 4-B entries -- the lost occupancy would cost more than the
+    // later passes cull stack entries at pop time (6-B entries) as long as 32 one-wave workgroups still fit a CU's 160 KB of LDS
+    // (5 KB each: up to 53 entries); a deeper tree keeps the 4-B entries -- the lost occupancy would cost more than the
     // cull returns (GPU-built tree of the 10M-triangle target, 56 entries: 0.465 vs 0.442 ms per frame)
     const bool cull = kCullPop && P.cull_pop && pass > 0 && (size_t)P.stack_lds * kRaysPerBlock * 6 <= 10240 / (128 / kTraceThreads);
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * (cull ? 6 : 4);
