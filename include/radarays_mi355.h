@@ -310,6 +310,20 @@ int rr_multi_set_motion_poses(rr_multi* m, const float* poses, size_t n);
 int rr_multi_simulate(rr_multi* m, const float pose_qxyzw_t[7], uint8_t* out_u8);
 int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8_t* out_imgs_u8);
 
+/* ---- environment switches (read at rr_create / at a build; none is needed in normal use) --------------------------
+ * RR_LANES (4)            frame buffer sets = batches that can be in flight (1..8)
+ * RR_STREAM_LANES (3)     lanes whose own stream rr_simulate_device rotates over
+ * RR_COPY_BLOCKS (8)      one-wave workgroups of a trace launch that trickle a deferred host copy; 0: never fold
+ * RR_FOLD_MIN_BUSY (2)    other lanes that must be busy for a host copy to be folded into the next batch
+ * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)
+ * RR_STACK_LDS (64)       traversal stack entries kept in LDS (lower: exercises the HBM spill path)
+ * RR_PASS0_AZ (16)        neighbouring azimuths per pass-0 wave (1, 2, 4, 8, 16)
+ * RR_ROCTX (0)            1: roctx ranges around the kernel enqueues (rocprofv3 --marker-trace)
+ * RR_TRACE_STATS          set: rr_get_stats prints the wave-level loop shape of the statistics build
+ * RR_BVH_THREADS, RR_BVH_VERBOSE, RR_BVH_ALPHA / _BETA / _BUDGET / _WZ   host builder: threads, phase times, and the
+ *                         BvhOptions (csrc/rr_bvh.h) for experiments;  RR_LBVH_NO_SPLIT: GPU builder without split clipping
+ * RR_MULTI_LOOPBACK (0)   1: rr_create_multi accepts one device several times (tests, see above) */
+
 #ifdef __cplusplus
 }
 #endif
