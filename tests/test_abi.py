@@ -154,3 +154,22 @@ def test_multi_plan_covers_every_frame_exactly_once(native_lib):
                     off = (a // n_loc) * block_stride + f * frame_stride + (a % n_loc) * C_
                     got[f, a] = gathered[off:off + C_]
             assert np.array_equal(got, want)
+
+
+def test_environment_switches_are_documented():
+    """Every RR_* environment switch the library reads is listed in the header's table, and the table lists no switch
+    that nothing reads."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "radarays_ros_amd", "csrc")
+    used = set()
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")):
+        used |= set(re.findall(r'getenv\("(RR_[A-Z0-9_]+)"\)', open(f).read()))
+    text = open(os.path.join(ROOT, "include", "radarays_mi355.h")).read()
+    block = text[text.index("---- environment switches"):]
+    listed = set(re.findall(r"RR_[A-Z0-9_]+", block))
+    # shorthand of the table: "RR_BVH_ALPHA / _BETA / _BUDGET / _WZ"
+    for suffix in re.findall(r"/ (_[A-Z]+)", block):
+        listed.add("RR_BVH" + suffix)
+    assert used - listed == set(), "undocumented: %s" % sorted(used - listed)
+    assert listed - used == set(), "documented but unused: %s" % sorted(listed - used)
