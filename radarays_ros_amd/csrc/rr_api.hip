@@ -30,6 +30,7 @@ bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s);
 void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s);
+void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s);
 }  // namespace rr
 
 using namespace rr;
@@ -77,6 +78,7 @@ struct Lane {
     DevBuf<float> d_img_f32;
     DevBuf<SegStats> d_seg_stats;
     DevBuf<float4> d_matsets;     // material sets of a parameter batch [n_sets][n_materials]
+    DevBuf<double> d_matset_limits;   // ... and their angles of total reflection (k_mat_limits)
     int last_n_seg = 0, last_n_passes = 0;
     int spill_stride = 0, stack_lds = 1;
 
@@ -124,6 +126,8 @@ struct rr_ctx {
     int smear_mode = 0;
 
     DevBuf<float4> d_qas, d_beams, d_materials;
+    DevBuf<double> d_mat_limits;   // [n_materials + 1]: angle of total reflection per material, last entry: v2 = 0.3f (same material on both sides)
+    double limit_same = 0.0;
     DevBuf<uint32_t> d_beam_order, d_beam_order2;
     DevBuf<int32_t> d_objmat;
     DevBuf<float> d_smear, d_noise, d_motion, d_decay;
@@ -316,6 +320,17 @@ int upload_tables(rr_ctx* c)
         m4[i] = make_float4(c->materials[i].velocity, c->materials[i].ambient, c->materials[i].diffuse, c->materials[i].specular);
     RR_HIP(c, c->d_materials.ensure(m4.size()));
     if (!m4.empty()) RR_HIP(c, hipMemcpy(c->d_materials.p, m4.data(), m4.size() * sizeof(float4), hipMemcpyHostToDevice));
+    {   // angles of total reflection, tabulated on the device (the very asin the kernels used to call per wave-pass)
+        std::vector<float4> mx(m4); mx.push_back(make_float4(0.3f, 0.f, 0.f, 0.f));
+        DevBuf<float4> tmp;
+        RR_HIP(c, tmp.ensure(mx.size()));
+        RR_HIP(c, hipMemcpy(tmp.p, mx.data(), mx.size() * sizeof(float4), hipMemcpyHostToDevice));
+        RR_HIP(c, c->d_mat_limits.ensure(mx.size()));
+        launch_mat_limits(tmp.p, mx.size(), c->d_mat_limits.p, nullptr);
+        RR_HIP(c, hipGetLastError());
+        RR_HIP(c, hipMemcpy(&c->limit_same, c->d_mat_limits.p + m4.size(), sizeof(double), hipMemcpyDeviceToHost));
+        tmp.release();
+    }
     RR_HIP(c, c->d_objmat.ensure(c->object_materials.size()));
     if (!c->object_materials.empty())
         RR_HIP(c, hipMemcpy(c->d_objmat.p, c->object_materials.data(), c->object_materials.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -425,6 +440,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
     P.tri_base4 = c->tri_base4;
     P.q_as = c->d_qas.p; P.beams = c->d_beams.p; P.beam_order = c->d_beam_order.p; P.beam_order2 = c->d_beam_order2.p; P.materials = c->d_materials.p;
+    P.mat_limits = c->d_mat_limits.p; P.limit_same = c->limit_same;
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr; P.noise_rows = c->noise_rows;
     P.decay = c->d_decay.p;
@@ -541,7 +557,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     fill_params(c, L, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
     P.n_loc = n_loc; P.n_frames = n_frames;
     if (d_matsets) {   // parameter batch: one pose, one material table per frame
-        P.materials = d_matsets; P.mat_stride = mat_stride; P.share_first = 1;
+        P.materials = d_matsets; P.mat_limits = L.d_matset_limits.p; P.mat_stride = mat_stride; P.share_first = 1;
         P.noise_rows = 1;     // every set is the SAME frame under another material table: one noise realisation (row 0)
         for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[k];
     } else
@@ -663,14 +679,14 @@ void rr_destroy(rr_ctx* c)
     (void)hipDeviceSynchronize();   // frames may still be in flight on the lanes' or the caller's streams
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release();
+    c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release(); c->d_mat_limits.release();
     c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_beam_order2.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
         L.d_refpos.release();
         L.d_hit.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
-        L.d_sigtmp.release(); L.d_sig.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_img_u8.release(); L.d_img_f32.release();
+        L.d_sigtmp.release(); L.d_sig.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_matset_limits.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         for (Lane::CopyRec& r : L.rec) if (r.ev) (void)hipEventDestroy(r.ev);
@@ -1044,10 +1060,12 @@ int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_ma
     if (L.d_matsets.n < (size_t)n_sets * n_mat) {
         RR_HIP(c, hipDeviceSynchronize());      // the table of this lane may still be read by an earlier step
         RR_HIP(c, L.d_matsets.ensure((size_t)n_sets * n_mat));
+        RR_HIP(c, L.d_matset_limits.ensure((size_t)n_sets * n_mat));
     }
     rc = prepare_lane(c, L, n_sets * g.n_angles); if (rc) return rc;
     // pageable source: the copy is staged before the call returns, the caller's array is free again
     RR_HIP(c, hipMemcpyAsync(L.d_matsets.p, sets, (size_t)n_sets * n_mat * sizeof(float4), hipMemcpyHostToDevice, s));
+    launch_mat_limits(L.d_matsets.p, (size_t)n_sets * n_mat, L.d_matset_limits.p, s);
     rc = run_frame(c, L, pose, 0, g.n_angles, nullptr, nullptr, s, n_sets, L.d_matsets.p, (int)n_mat); if (rc) return rc;
     { TimedScope t(c, s, "assemble");
       launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,

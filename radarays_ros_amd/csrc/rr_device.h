@@ -87,6 +87,8 @@ struct Params {
     const uint32_t* beam_order;  // [n_beam] trace slot -> beam index of pass 0 (rows of equal elevation: equally long rays share a wave)
     const uint32_t* beam_order2; // [n_beam] the order the LATER passes inherit (yaw-major rows)
     const float4* materials;     // [n_materials] velocity, ambient, diffuse, specular
+    const double* mat_limits;    // per entry of `materials`: the angle of total reflection for a wave that meets the material coming from air (k_mat_limits)
+    double limit_same;           // the same angle for v2 = v1 = 0.3 (both sides the same material)
     const int32_t* object_materials;
     const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)
     const float* noise_rnd;      // [noise_rows][n_angles] or null; frame f of a batch reads row f % noise_rows

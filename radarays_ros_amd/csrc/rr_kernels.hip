@@ -376,7 +376,26 @@ __device__ inline float acosf_ref(float x) { return (float)acos((double)x); }
 
 // radar_algorithms.h:55-139 (only dir + energy of both results are used,
 // RadarCPU.cpp:285-286,364-365)
-__device__ inline void fresnel_split(V3 n, const V3 d, const double energy, const double v1, const double v2,
+// angle of total reflection, radar_algorithms.h:77-83: asin(n2 / n1) where defined, else 100.  It depends on the pair of
+// velocities only, i.e. on the material entry: tabulated once per material table instead of once per wave-pass
+__device__ inline double fresnel_angle_limit(double v1, double v2)
+{
+    const double n1 = v2, n2 = v1;
+    double angle_limit = 100.0;
+    if (n1 > 0.0) { const double n21 = n2 / n1; if (fabs(n21) <= 1.0) angle_limit = asin(n21); }
+    return angle_limit;
+}
+__global__ void k_mat_limits(const float4* materials, size_t n, double* limits)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) limits[i] = fresnel_angle_limit(0.3, (double)materials[i].x);
+}
+void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_mat_limits, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, materials, n, limits);
+}
+
+__device__ inline void fresnel_split(V3 n, const V3 d, const double energy, const double v1, const double v2, const double angle_limit,
                                      V3& rdir, double& renergy, V3& tdir, double& tenergy)
 {
     const double polarization = 0.5;   // RadarCPU.cpp:108
@@ -386,9 +405,6 @@ __device__ inline void fresnel_split(V3 n, const V3 d, const double energy, cons
     tdir = { 0.0f, 0.0f, 0.0f };
     bool transmitted = false;          // false: tdir stays the zero vector of radar_algorithms.h:66
     if (n1 > 0.0) {
-        const double n21 = n2 / n1;
-        double angle_limit = 100.0;
-        if (fabs(n21) <= 1.0) angle_limit = asin(n21);
         if (incidence_angle <= angle_limit) {
             if (v_dot(n, d) > 0.0f) n = v_neg(n);   // :92
             if (n2 > 0.0) {
@@ -547,9 +563,10 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
         } else {
             const float4 m = P.materials[(size_t)(seg / P.n_loc) * P.mat_stride + mat_refr];
             const float v_refraction = (mat != mat_refr) ? m.x : (float)0.3;
+            const double angle_limit = (mat != mat_refr) ? P.mat_limits[(size_t)(seg / P.n_loc) * P.mat_stride + mat_refr] : P.limit_same;
 
             V3 rdir, tdir; double renergy, tenergy;
-            fresnel_split(normal, dir_in, energy, 0.3, (double)v_refraction, rdir, renergy, tdir, tenergy);
+            fresnel_split(normal, dir_in, energy, 0.3, (double)v_refraction, angle_limit, rdir, renergy, tdir, tenergy);
 
             const float skip_dist = 0.001f;   // RadarCPU.cpp:374
             if (renergy > (double)P.thr)      // :288
