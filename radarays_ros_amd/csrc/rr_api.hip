@@ -126,8 +126,8 @@ struct rr_ctx {
     int smear_mode = 0;
 
     DevBuf<float4> d_qas, d_beams, d_materials;
-    DevBuf<double> d_mat_limits;   // [n_materials + 1]: angle of total reflection per material, last entry: v2 = 0.3f (same material on both sides)
-    double limit_same = 0.0;
+    DevBuf<double> d_mat_limits;   // [n_materials]: angle of total reflection per material
+    double limit_same = 0.0;       // ... and for v2 = 0.3f (the same material on both sides): computed once, at rr_create
     DevBuf<uint32_t> d_beam_order, d_beam_order2;
     DevBuf<int32_t> d_objmat;
     DevBuf<float> d_smear, d_noise, d_motion, d_decay;
@@ -320,17 +320,10 @@ int upload_tables(rr_ctx* c)
         m4[i] = make_float4(c->materials[i].velocity, c->materials[i].ambient, c->materials[i].diffuse, c->materials[i].specular);
     RR_HIP(c, c->d_materials.ensure(m4.size()));
     if (!m4.empty()) RR_HIP(c, hipMemcpy(c->d_materials.p, m4.data(), m4.size() * sizeof(float4), hipMemcpyHostToDevice));
-    {   // angles of total reflection, tabulated on the device (the very asin the kernels used to call per wave-pass)
-        std::vector<float4> mx(m4); mx.push_back(make_float4(0.3f, 0.f, 0.f, 0.f));
-        DevBuf<float4> tmp;
-        RR_HIP(c, tmp.ensure(mx.size()));
-        RR_HIP(c, hipMemcpy(tmp.p, mx.data(), mx.size() * sizeof(float4), hipMemcpyHostToDevice));
-        RR_HIP(c, c->d_mat_limits.ensure(mx.size()));
-        launch_mat_limits(tmp.p, mx.size(), c->d_mat_limits.p, nullptr);
-        RR_HIP(c, hipGetLastError());
-        RR_HIP(c, hipMemcpy(&c->limit_same, c->d_mat_limits.p + m4.size(), sizeof(double), hipMemcpyDeviceToHost));
-        tmp.release();
-    }
+    // angles of total reflection, tabulated on the device (the very asin the kernels used to call per wave-pass)
+    RR_HIP(c, c->d_mat_limits.ensure(m4.size()));
+    launch_mat_limits(c->d_materials.p, m4.size(), c->d_mat_limits.p, nullptr);
+    RR_HIP(c, hipGetLastError());
     RR_HIP(c, c->d_objmat.ensure(c->object_materials.size()));
     if (!c->object_materials.empty())
         RR_HIP(c, hipMemcpy(c->d_objmat.p, c->object_materials.data(), c->object_materials.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -659,6 +652,15 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
     if (getenv("RR_CULL_POP")) c->cull_pop = atoi(getenv("RR_CULL_POP")) != 0;
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
+    {   // the one angle of total reflection that does not depend on the material table
+        const float4 same = make_float4(0.3f, 0.f, 0.f, 0.f);
+        DevBuf<float4> m1; DevBuf<double> l1;
+        bool ok = m1.ensure(1) == hipSuccess && l1.ensure(1) == hipSuccess &&
+                  hipMemcpy(m1.p, &same, sizeof(same), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) { launch_mat_limits(m1.p, 1, l1.p, nullptr); ok = hipMemcpy(&c->limit_same, l1.p, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess; }
+        m1.release(); l1.release();
+        if (!ok) { g_create_error = "rr_create: device set-up failed"; rr_destroy(c); return nullptr; }
+    }
     c->lanes.resize((size_t)n_lanes);
     for (Lane& L : c->lanes) {
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
