@@ -843,11 +843,13 @@ void launch_decay_table(float* decay, int n_cells, double resolution, double ene
 // so the column is bit-reproducible and equal to the sequential CPU loop.
 // ---------------------------------------------------------------------------
 constexpr int kSigChunk = 2048;
-constexpr int kColThreads = 256;   // 4 waves per azimuth column (measured: 512 -0.5..1 %, 1024 -12..26 %)
-constexpr int kColWaves = kColThreads / 64;
+// threads per azimuth column: 4 waves when a launch brings thousands of columns (frame batches: +0.5..1 % against 8 waves;
+// 16 waves lose 12-26 %), 8 waves for the few hundred columns of a single frame (its k_column then takes 80 instead of 91 us)
 
+template <int kColThreads>
 __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 {
+    constexpr int kColWaves = kColThreads / 64;
     extern __shared__ float lds_col[];              // [n_cells] slice
     // replay phase: the current chunk of signals; noise phase: the four Perlin column tables
     __shared__ __align__(16) unsigned char s_union[4 * kPerlinRow * sizeof(double2)];
@@ -1238,8 +1240,10 @@ void launch_scan(const Params& P, int pass, hipStream_t s)
 
 void launch_column(const Params& P, hipStream_t s)
 {
-    dim3 grid(P.n_seg), block(kColThreads);
-    hipLaunchKernelGGL(k_column, grid, block, (size_t)P.n_cells * sizeof(float), s, P);
+    dim3 grid(P.n_seg);
+    const size_t lds = (size_t)P.n_cells * sizeof(float);
+    if (P.n_seg >= 1024) hipLaunchKernelGGL(k_column<256>, grid, dim3(256), lds, s, P);
+    else hipLaunchKernelGGL(k_column<512>, grid, dim3(512), lds, s, P);
 }
 
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
