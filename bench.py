@@ -84,6 +84,53 @@ def pct(v, q):
     return float(v[min(len(v) - 1, int(q * len(v)))]) if len(v) else 0.0
 
 
+def visible_gpus():
+    """Number of GPUs this process could use, WITHOUT initialising the HIP runtime: the KFD topology in sysfs
+    (a node with SIMDs is a GPU), narrowed by HIP_/ROCR_VISIBLE_DEVICES; torch.cuda.device_count() -- which does not
+    initialise the GPU on this image -- where sysfs is not readable."""
+    n = None
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(top):
+            with open(os.path.join(top, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = None
+    if not n:
+        import torch
+        return int(torch.cuda.device_count())
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def self_launch(n_gpus):
+    """Runs this very command under `python -m torch.distributed.run` with one rank per GPU (child process; its
+    rank 0 prints the JSON line on our stdout) and returns its exit code.  Fewer GPUs than asked for: one clear
+    line, non-zero, at once."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if have < n_gpus:
+        print("bench.py: --gpus %d asked for, but this box shows %d GPU%s -- not launched" % (n_gpus, have, "" if have == 1 else "s"),
+              file=sys.stderr, flush=True)
+        return 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,7 +154,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything in this
+            # process touches the GPU (the parent only counts devices and waits for the child)
+            raise SystemExit(self_launch(args.gpus))
         args.gpus = world
 
     import torch

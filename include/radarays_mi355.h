@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 3
+#define RR_ABI_VERSION 4
 #define RR_MAX_BATCH 64   /* frames (poses or material sets) one call renders in one set of launches */
 
 typedef struct rr_ctx rr_ctx;
@@ -195,7 +195,10 @@ int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint
  * the lane send what is still waiting with a plain copy.  Issue batches on up to four streams (HIP maps streams onto
  * four hardware queues) and hand the buffers out from a ring twice as deep as the batches in flight.  h_imgs_u8
  * should be page-locked (rr_host_alloc / rr_host_free = hipHostMalloc); a pageable buffer works through the plain copy.
- * rr_destroy drops images that nobody waited for. */
+ * rr_destroy drops images that nobody waited for.
+ * `stream` must stay valid until rr_wait_host() / rr_synchronize() has returned for this buffer: a copy that did not
+ * ride on a later batch is issued on it then.  "Returns at once" has two exceptions: a lane whose two previous
+ * deliveries are both still in flight makes the call wait for the older one, and so does a buffer reallocation. */
 int rr_simulate_batch_host_async(rr_ctx* ctx, const float* poses, int n_frames, uint8_t* h_imgs_u8, void* stream);
 int rr_wait_host(rr_ctx* ctx, const void* h_imgs_u8);
 void* rr_host_alloc(size_t bytes);
@@ -245,6 +248,13 @@ int rr_simulate_device(rr_ctx* ctx, const float pose_qxyzw_t[7], uint8_t* d_img_
  * (such a frame is truncated; the synchronous rr_simulate returns the same codes itself). */
 int rr_synchronize(rr_ctx* ctx, void* stream);
 
+/* Pipelined callers that must not drain the device to learn about an error: enqueues on `stream` (the one the LAST
+ * *_device / *_host_async call ran on) a 4-byte copy of the error bits of the frame lane that call used (bit 0: wave /
+ * signal queue overflow, bit 1: object / material id outside the tables; accumulated since the last rr_synchronize, which
+ * reports and clears them) into *h_bits.  h_bits should be page-locked (rr_host_alloc); it is valid once `stream` has
+ * reached this point.  rr_multi uses it per batch. */
+int rr_peek_error_bits_async(rr_ctx* ctx, uint32_t* h_bits, void* stream);
+
 /* Counters of the last frame (synchronises the ctx stream). */
 int rr_get_stats(rr_ctx* ctx, rr_stats* stats);
 
@@ -276,10 +286,11 @@ int rr_reserve_timing_events(rr_ctx* ctx, size_t n);
  * The reference creates ONE backend object per process (src/radar_simulator.cpp:145-176) and fans out inside it
  * (OpenMP over azimuths, RadarCPU.cpp:155).  rr_multi is that object for n GPUs: one rr_ctx per device, mesh and
  * parameters replicated, device i renders the contiguous azimuth block rr_partition(n_angles, n, i) of every frame
- * of a call in one set of launches, ONE RCCL collective per call over xGMI brings the blocks to device 0
- * (ncclAllGather for equal blocks, a group of send/recv pairs for ragged ones), which transposes them into the
- * mono8 images and copies them to the caller's host buffer.  With one device no collective runs and the images
- * are byte-identical to rr_simulate's.  RCCL (librccl.so.1) is loaded at run time when n > 1. */
+ * of a call in one set of launches, ONE RCCL collective per call over xGMI gathers the blocks on device 0 (one
+ * group of send / recv pairs to the root: one piece per device for equal blocks, one per device and frame for ragged
+ * ones; no other device receives anything), which transposes them into the mono8 images and copies them to the
+ * caller's host buffer.  With one device no collective runs and the images are byte-identical to rr_simulate's.
+ * RCCL (librccl.so.1) is loaded at run time when n > 1. */
 /* (Test switch RR_MULTI_LOOPBACK=1: a device may be listed several times; the collective is then replaced by
  * device-to-device copies along the same plan -- the n > 1 path on a one-GPU box, minus the RCCL calls.) */
 typedef struct rr_multi rr_multi;
@@ -309,6 +320,16 @@ int rr_multi_set_motion_poses(rr_multi* m, const float* poses, size_t n);
  * [n_frames][n_cells][n_angles], synchronous; -7 / -8 like rr_simulate when a device reports an overflow / bad id */
 int rr_multi_simulate(rr_multi* m, const float pose_qxyzw_t[7], uint8_t* out_u8);
 int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8_t* out_imgs_u8);
+/* Pipelined form (what a node that streams frames calls, radar_simulator.cpp:197-212): enqueues the batch and returns;
+ * the images are complete only after rr_multi_wait(m, h_imgs_u8) (NULL: every batch in flight), which also reports a
+ * -7 / -8 of that batch.  Up to RR_MULTI_SLOTS (default 4, 1..8) batches are in flight -- the render of batch k+1
+ * overlaps the collective, the transpose and the D2H copy of batch k; a call that finds its slot still busy waits for
+ * that older batch first.  h_imgs_u8 should be page-locked (rr_host_alloc) and handed out from a ring at least as deep
+ * as the slots; it must stay valid and unread until waited for.  After any error return nothing of the object is in
+ * flight any more (every device drained, error bits cleared): the caller may free its buffers.
+ * With ONE device a batch takes rr_simulate_batch_host_async's route (deferred, trickled host copy). */
+int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames, uint8_t* h_imgs_u8);
+int rr_multi_wait(rr_multi* m, const void* h_imgs_u8);
 
 /* ---- environment switches (read at rr_create / at a build; none is needed in normal use) --------------------------
  * RR_LANES (4)            frame buffer sets = batches that can be in flight (1..8)
@@ -322,7 +343,8 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
  * RR_TRACE_STATS          set: rr_get_stats prints the wave-level loop shape of the statistics build
  * RR_BVH_THREADS, RR_BVH_VERBOSE, RR_BVH_ALPHA / _BETA / _BUDGET / _WZ   host builder: threads, phase times, and the
  *                         BvhOptions (csrc/rr_bvh.h) for experiments;  RR_LBVH_NO_SPLIT: GPU builder without split clipping
- * RR_MULTI_LOOPBACK (0)   1: rr_create_multi accepts one device several times (tests, see above) */
+ * RR_MULTI_LOOPBACK (0)   1: rr_create_multi accepts one device several times (tests, see above)
+ * RR_MULTI_SLOTS (4)      batches rr_multi keeps in flight (streams + buffer sets per device, 1..8) */
 
 #ifdef __cplusplus
 }

@@ -157,6 +157,8 @@ struct rr_ctx {
         hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
     }
 
+    void* h_frame = nullptr; size_t h_frame_bytes = 0;   // page-locked: error bits + per-pass counters of rr_simulate's frame
+
     bool roctx = false;
     int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
     int cull_pop = 1;            // k_trace's later passes drop stack entries at pop time (RR_CULL_POP=0: off; the images are the same either way)
@@ -324,6 +326,8 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, c->d_mat_limits.ensure(m4.size()));
     launch_mat_limits(c->d_materials.p, m4.size(), c->d_mat_limits.p, nullptr);
     RR_HIP(c, hipGetLastError());
+    // the frame streams are non-blocking: nothing orders them behind the NULL stream this table was launched on
+    RR_HIP(c, hipStreamSynchronize(nullptr));
     RR_HIP(c, c->d_objmat.ensure(c->object_materials.size()));
     if (!c->object_materials.empty())
         RR_HIP(c, hipMemcpy(c->d_objmat.p, c->object_materials.data(), c->object_materials.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -695,6 +699,7 @@ void rr_destroy(rr_ctx* c)
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->h_frame) (void)hipHostFree(c->h_frame);
     delete c;
 }
 
@@ -706,12 +711,16 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
     Bvh4 bvh; std::string err;
+    // the builder allocates hundreds of MB and starts threads: whatever it throws (bad_alloc, system_error) stops here
+    try {
     if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err)) return fail(c, -4, err);
     if (bvh.spatial_splits > 0 && bvh.nodes.size() * 8 + (bvh.tris.size() + 4) * 3 >= (1ull << 28)) {
         // the parts spatial splits add pushed the tree over the 28-bit reference range: build without them
         BvhOptions plain; plain.sbvh_alpha = -1.0f;
         if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err, 0, &plain)) return fail(c, -4, err);
     }
+    } catch (const std::exception& ex) { return fail(c, -4, std::string("rr_set_mesh: host BVH build failed: ") + ex.what());
+    } catch (...) { return fail(c, -4, "rr_set_mesh: host BVH build failed"); }
     // frames in flight on the lane streams or a caller's stream (all non-blocking: a blocking hipMemcpy
     // does not order against them) still trace the old tree
     RR_HIP(c, hipDeviceSynchronize());
@@ -1151,12 +1160,18 @@ int rr_simulate_device(rr_ctx* c, const float pose[7], uint8_t* d_img_u8, void* 
         Lane& L = c->lanes[0];
         { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
         c->last_lane = 0;
+        // With ONE lane every launch of the frame goes to the caller's stream, so the call can be CAPTURED into a hipGraph
+        // (hipStreamBeginCapture on `user`, this call, hipStreamEndCapture) and replayed -- tools/cpp_bench.cpp `graph`.  While
+        // capturing, the lane's hand-over event stays out of it (an event recorded outside the capture cannot be waited
+        // for inside): the caller keeps other work off the context while such a graph runs.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(user, &cap);
+        const bool capturing = cap == hipStreamCaptureStatusActive;
         // the lane's previous frame may have run on ANOTHER caller stream (or a flushed host copy may still read the lane)
-        if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(user, L.ev_consumed, 0));
+        if (L.pending_consume && !capturing) RR_HIP(c, hipStreamWaitEvent(user, L.ev_consumed, 0));
         rc = run_frame(c, L, pose, 0, A, nullptr, nullptr, user); if (rc) return rc;
         rc = rr_assemble_image_device(c, L.d_cols_u8.p, d_img_u8, user); if (rc) return rc;
-        RR_HIP(c, hipEventRecord(L.ev_consumed, user));
-        L.pending_consume = true;
+        if (!capturing) { RR_HIP(c, hipEventRecord(L.ev_consumed, user)); L.pending_consume = true; }
         return 0;
     }
     // Frame pipelining: trace/shade/scan/column of this frame run on the lane's own stream
@@ -1203,6 +1218,17 @@ int rr_synchronize(rr_ctx* c, void* stream)
     return 0;
 }
 
+int rr_peek_error_bits_async(rr_ctx* c, uint32_t* h_bits, void* stream)
+{
+    if (!c) return -1;
+    if (!h_bits) return fail(c, -3, "rr_peek_error_bits_async: null pointer");
+    RR_HIP(c, hipSetDevice(c->device));
+    Lane& L = c->lanes[c->last_lane];
+    if (!L.d_sticky.p) { *h_bits = 0; return 0; }     // no frame has run on this lane yet
+    RR_HIP(c, hipMemcpyAsync(h_bits, L.d_sticky.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream ? (hipStream_t)stream : c->stream));
+    return 0;
+}
+
 int rr_get_stats(rr_ctx* c, rr_stats* st)
 {
     if (!c || !st) return -1;
@@ -1242,9 +1268,24 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
     Lane& L = c->lanes[0];
     { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = 0;
-    RR_HIP(c, hipDeviceSynchronize());
+    // The reference's call shape: one synchronous simulate() per frame (radar_simulator.cpp:197-212).  Its latency is
+    // the chain of kernels plus what the host adds around it, so the host adds as little as it can: the frame is
+    // ordered behind the lane's previous user by an event (no device-wide drain), the error bits and the per-pass
+    // counters ride home behind the image on the same stream, and ONE hipStreamSynchronize ends the call.
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(c->stream, L.ev_consumed, 0));
     rc = run_frame(c, L, pose, az_begin, az_end, nullptr, nullptr, c->stream, 1, nullptr, 0, out_f32 != nullptr);
     if (rc) return rc;
+    const size_t n_st = (size_t)n_seg * (size_t)std::max(1, g.n_reflections);
+    const size_t need = sizeof(Counters) + (stats ? n_st * sizeof(SegStats) : 0);
+    if (c->h_frame_bytes < need) {
+        if (c->h_frame) (void)hipHostFree(c->h_frame);
+        c->h_frame = nullptr; c->h_frame_bytes = 0;
+        RR_HIP(c, hipHostMalloc(&c->h_frame, need + 4096, hipHostMallocDefault));
+        c->h_frame_bytes = need + 4096;
+    }
+    Counters* h_cnt = reinterpret_cast<Counters*>(c->h_frame);
+    SegStats* h_ss = reinterpret_cast<SegStats*>(h_cnt + 1);
+    std::vector<uint8_t> h8; std::vector<float> hf;
     if (n_seg == g.n_angles) {
         // whole frame: transpose on the GPU, one D2H copy straight into the caller's row-major buffer
         const size_t npx = (size_t)g.n_cells * g.n_angles;
@@ -1258,13 +1299,19 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
             launch_assemble_f32(L.d_cols_f32.p, L.d_img_f32.p, g.n_angles, g.n_cells, g.scroll_image, c->stream);
             RR_HIP(c, hipMemcpyAsync(out_f32, L.d_img_f32.p, npx * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         }
-        RR_HIP(c, hipStreamSynchronize(c->stream));
     } else {
-        std::vector<uint8_t> h8((size_t)n_seg * g.n_cells);
-        std::vector<float> hf(out_f32 ? (size_t)n_seg * g.n_cells : 0);
+        h8.resize((size_t)n_seg * g.n_cells);
+        hf.resize(out_f32 ? (size_t)n_seg * g.n_cells : 0);
         RR_HIP(c, hipMemcpyAsync(h8.data(), L.d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
         if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), L.d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        RR_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    RR_HIP(c, hipMemcpyAsync(h_cnt, L.d_counters.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    if (stats && L.d_seg_stats.p && g.n_reflections > 0)
+        RR_HIP(c, hipMemcpyAsync(h_ss, L.d_seg_stats.p, n_st * sizeof(SegStats), hipMemcpyDeviceToHost, c->stream));
+    RR_HIP(c, hipEventRecord(L.ev_consumed, c->stream));
+    L.pending_consume = true;
+    RR_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_seg != g.n_angles) {
         for (int s = 0; s < n_seg; s++) {
             const int col = (g.scroll_image + az_begin + s) % g.n_angles;   // RadarCPU.cpp:457
             for (int i = 0; i < g.n_cells; i++) {
@@ -1273,15 +1320,13 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
             }
         }
     }
-    uint32_t overflow = 0;
+    const uint32_t overflow = h_cnt->overflow;
     if (stats) {
-        rr_stats st;
-        rc = rr_get_stats(c, &st); if (rc) return rc;
-        *stats = st; overflow = st.overflow;
-    } else {
-        Counters h;
-        RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
-        overflow = h.overflow;
+        std::memset(stats, 0, sizeof(*stats));
+        stats->nodes_visited = h_cnt->nodes; stats->tris_tested = h_cnt->tris; stats->overflow = overflow;
+        if (g.n_reflections > 0)
+            for (size_t k = 0; k < n_st; k++) { stats->wave_passes += h_ss[k].wave_passes; stats->hits += h_ss[k].hits; stats->signals += h_ss[k].signals; }
+        if (getenv("RR_TRACE_STATS")) { rr_stats tmp; (void)rr_get_stats(c, &tmp); }     // prints the wave-level loop shape
     }
     if (overflow) RR_HIP(c, hipMemset(L.d_sticky.p, 0, sizeof(uint32_t)));   // reported here, not again by rr_synchronize
     if (overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");

@@ -22,11 +22,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <future>
 #include <limits>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <system_error>
 #include <vector>
 #include <thread>
 
@@ -281,19 +283,27 @@ struct Builder {
         if (nchunks <= 1) { if (n) f((size_t)0, (size_t)0, n); return; }
         const int extra = acquire((int)std::min<size_t>(nchunks - 1, 255));
         std::atomic<size_t> next{0};
+        // an exception of f (bad_alloc) must not leave a joinable thread behind (std::terminate): the first one is kept,
+        // the remaining chunks are skipped, and it is rethrown after the joins -- rr_set_mesh turns it into an error code
+        std::exception_ptr err; std::atomic<bool> failed_here{false};
         auto work = [&] {
-            for (;;) {
-                const size_t c = next.fetch_add(1);
-                if (c >= nchunks) break;
-                f(c, c * kChunk, std::min(n, (c + 1) * kChunk));
-            }
+            try {
+                for (;;) {
+                    const size_t c = next.fetch_add(1);
+                    if (c >= nchunks || failed_here.load(std::memory_order_relaxed)) break;
+                    f(c, c * kChunk, std::min(n, (c + 1) * kChunk));
+                }
+            } catch (...) { if (!failed_here.exchange(true)) err = std::current_exception(); }
         };
         std::vector<std::thread> th;
-        th.reserve((size_t)extra);
-        for (int i = 0; i < extra; i++) th.emplace_back(work);
+        try {
+            th.reserve((size_t)extra);
+            for (int i = 0; i < extra; i++) th.emplace_back(work);     // no thread to be had: the chunks run on the ones that started
+        } catch (...) {}
         work();
         for (auto& t : th) t.join();
         release(extra);
+        if (err) std::rethrow_exception(err);
     }
     static size_t n_chunks(size_t n) { return std::max<size_t>(1, (n + kChunk - 1) / kChunk); }
 
@@ -425,9 +435,13 @@ struct Builder {
     }
 
     void recurse(uint32_t left, RefVec& L, const Bounds& bl, RefVec& R, const Bounds& br, size_t count) {
+        std::future<void> fut; bool forked = false;
         if (count >= kParallelMin && acquire(1) == 1) {
-            auto fut = std::async(std::launch::async, [this, left, &L, &bl] { build(left, L, bl); flush_local(); });
-            build(left + 1, R, br);
+            try { fut = std::async(std::launch::async, [this, left, &L, &bl] { build(left, L, bl); flush_local(); }); forked = true; }
+            catch (const std::system_error&) { release(1); }          // no thread to be had: inline below
+        }
+        if (forked) {
+            build(left + 1, R, br);       // (if this throws, the future's destructor still waits for the other half)
             fut.get();
             release(1);
         } else {
@@ -600,8 +614,11 @@ struct Collapser {
             const Node2& c = n2[cand[i]];
             if (c.count) { m.nt += c.count; m.sah += (double)c.box.half_area() * c.count; continue; }
             m.sah += (double)c.box.half_area();
-            if (level < 4 && take_thread()) { async_[i] = true; fut[i] = std::async(std::launch::async, [this, ci = cand[i], level] { return measure(ci, level + 1); }); }
-            else sub[i] = measure(cand[i], level + 1);
+            if (level < 4 && take_thread()) {
+                try { fut[i] = std::async(std::launch::async, [this, ci = cand[i], level] { return measure(ci, level + 1); }); async_[i] = true; }
+                catch (const std::system_error&) { tasks_left.fetch_add(1); }
+            }
+            if (!async_[i]) sub[i] = measure(cand[i], level + 1);
         }
         for (int i = 0; i < nc; i++) {
             if (n2[cand[i]].count) continue;
@@ -664,9 +681,10 @@ struct Collapser {
         for (int i = 0; i < nc; i++) {
             if (n2[cand[i]].count) continue;
             if (level < 4 && n4[cand[i]] > 4096 && take_thread()) {
-                async_[i] = true;
-                fut[i] = std::async(std::launch::async, [this, a = cs[i], b = cand[i], c2 = cd[i], d = ct[i], level] { emit(a, b, c2, d, level + 1); });
-            } else emit(cs[i], cand[i], cd[i], ct[i], level + 1);
+                try { fut[i] = std::async(std::launch::async, [this, a = cs[i], b = cand[i], c2 = cd[i], d = ct[i], level] { emit(a, b, c2, d, level + 1); }); async_[i] = true; }
+                catch (const std::system_error&) { tasks_left.fetch_add(1); }
+            }
+            if (!async_[i]) emit(cs[i], cand[i], cd[i], ct[i], level + 1);
         }
         for (int i = 0; i < nc; i++) if (async_[i]) { fut[i].get(); tasks_left.fetch_add(1); }
     }

@@ -395,12 +395,13 @@ void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStr
     if (n) hipLaunchKernelGGL(k_mat_limits, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, materials, n, limits);
 }
 
-__device__ inline void fresnel_split(V3 n, const V3 d, const double energy, const double v1, const double v2, const double angle_limit,
-                                     V3& rdir, double& renergy, V3& tdir, double& tenergy)
+__device__ inline void fresnel_split(V3 n, const V3 d, const float incidence_f, const double energy, const double v1, const double v2,
+                                     const double angle_limit, V3& rdir, double& renergy, V3& tdir, double& tenergy)
 {
     const double polarization = 0.5;   // RadarCPU.cpp:108
     const double n1 = v2, n2 = v1;     // radar_algorithms.h:62-63
-    const double incidence_angle = (double)acosf_ref(v_dot(v_neg(d), n));
+    // acosf(-d . n): the caller computed it (the BRDF angle of RadarCPU.cpp:308 is the same expression on the same values)
+    const double incidence_angle = (double)incidence_f;
     rdir = v_add(d, v_scale(v_scale(n, 2.0f), v_dot(v_neg(n), d)));   // :73
     tdir = { 0.0f, 0.0f, 0.0f };
     bool transmitted = false;          // false: tdir stays the zero vector of radar_algorithms.h:66
@@ -416,27 +417,47 @@ __device__ inline void fresnel_split(V3 n, const V3 d, const double energy, cons
             }
         }
     }
-    // :106.  For the zero vector the dot product is (+-)0 and acosf(+-0) is the f32 value of pi/2: no need to
-    // run the f64 acos for every wave that meets an opaque material (v = 0: the KAIST wall) or total reflection
-    const double refraction_angle = transmitted ? (double)acosf_ref(v_dot(tdir, v_neg(n))) : (double)1.57079637050628662109375f;
     double rs, rp;
     const double eps = 0.0001;
-    const double s = incidence_angle + refraction_angle;
-    if (s < eps) {
-        rs = (n1 - n2) / (n1 + n2);
-        rp = rs;
-    } else if (s > M_PI - eps) {
-        rs = 1.0; rp = 1.0;
+    if (!transmitted) {
+        // :106 for the zero vector: the dot product is (+-)0 and acosf(+-0) is the f32 value of pi/2 -- every wave that meets
+        // an opaque material (v = 0: the KAIST wall) or is totally reflected.  h = (double)(float)(pi/2) is a CONSTANT, so
+        // sin / cos of (incidence -+ h) come from ONE sincos(incidence) and the angle-sum identities with sin(h), cos(h)
+        // as correctly rounded f64 constants, instead of two sincos with two argument reductions.  cos(h) = -4.37e-8 (h is
+        // not pi/2: that is what makes R_eff exceed 1 by 1e-7 for v2 = 0) -- each sum below has one term of
+        // that size and one >= 1e-4 (the s > pi - eps branch takes everything nearer to grazing), so nothing cancels: the
+        // results are within 2 ulp(f64) of the two-sincos form, the freedom the GPU's libm has against the host's anyway.
+        const double h = (double)1.57079637050628662109375f;
+        const double ch = -0x1.777a5cf72ceccp-25, sh = 0x1.ffffffffffff7p-1;
+        const double s = incidence_angle + h;      // > eps always
+        if (s > M_PI - eps) { rs = 1.0; rp = 1.0; }
+        else {
+            double si, ci;
+            sincos(incidence_angle, &si, &ci);
+            const double a = si * ch, b = ci * sh, e = ci * ch, f = si * sh;
+            const double sd = a - b, ss = a + b, cd = e + f, cs = e - f;     // sin / cos of (incidence - h), (incidence + h)
+            rs = -sd / ss;
+            rp = (sd / cd) / (ss / cs);
+        }
     } else {
-        // rs = -sin(df) / sin(s), rp = tan(df) / tan(s)  (radar_algorithms.h:116-121).  One sincos per angle
-        // (one argument reduction) instead of sin + tan; tan = sin / cos is within an ulp of libm's tan --
-        // the same freedom the GPU's libm already has against the host's
-        const double df = incidence_angle - refraction_angle;
-        double sd, cd, ss, cs;
-        sincos(df, &sd, &cd);
-        sincos(s, &ss, &cs);
-        rs = -sd / ss;
-        rp = (sd / cd) / (ss / cs);
+        const double refraction_angle = (double)acosf_ref(v_dot(tdir, v_neg(n)));   // :106
+        const double s = incidence_angle + refraction_angle;
+        if (s < eps) {
+            rs = (n1 - n2) / (n1 + n2);
+            rp = rs;
+        } else if (s > M_PI - eps) {
+            rs = 1.0; rp = 1.0;
+        } else {
+            // rs = -sin(df) / sin(s), rp = tan(df) / tan(s)  (radar_algorithms.h:116-121).  One sincos per angle
+            // (one argument reduction) instead of sin + tan; tan = sin / cos is within an ulp of libm's tan --
+            // the same freedom the GPU's libm already has against the host's
+            const double df = incidence_angle - refraction_angle;
+            double sd, cd, ss, cs;
+            sincos(df, &sd, &cd);
+            sincos(s, &ss, &cs);
+            rs = -sd / ss;
+            rp = (sd / cd) / (ss / cs);
+        }
     }
     const double Rs = rs * rs, Rp = rp * rp;
     const double Reff = polarization * Rs + (1.0 - polarization) * Rp;
@@ -566,7 +587,8 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
             const double angle_limit = (mat != mat_refr) ? P.mat_limits[(size_t)(seg / P.n_loc) * P.mat_stride + mat_refr] : P.limit_same;
 
             V3 rdir, tdir; double renergy, tenergy;
-            fresnel_split(normal, dir_in, energy, 0.3, (double)v_refraction, angle_limit, rdir, renergy, tdir, tenergy);
+            const float incidence_angle = acosf_ref(v_dot(v_neg(dir_in), normal));   // radar_algorithms.h:69 and RadarCPU.cpp:308: one value
+            fresnel_split(normal, dir_in, incidence_angle, energy, 0.3, (double)v_refraction, angle_limit, rdir, renergy, tdir, tenergy);
 
             const float skip_dist = 0.001f;   // RadarCPU.cpp:374
             if (renergy > (double)P.thr)      // :288
@@ -581,7 +603,6 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
                 }
                 if ((int)mat == P.material_id_air)   // :302
                 {
-                    const float incidence_angle = acosf_ref(v_dot(v_neg(dir_in), normal));   // :308
                     const float ret = back_reflection_shader(incidence_angle, (float)renergy, m.y, m.z, m.w, P.brdf_model);
                     if (pass == 0 || P.record_multi_reflection) {   // :319
                         const float time_back = (float)(time * 2.0);

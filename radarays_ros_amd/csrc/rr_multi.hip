@@ -3,10 +3,14 @@
 //
 // One process, one rr_ctx per device, mesh / parameters replicated, device i renders the contiguous azimuth block
 // rr_partition(n_angles, n, i) of every frame of a call in ONE set of launches on its own stream; ONE RCCL
-// collective per call assembles the frames on device 0:
-//     equal blocks  : ncclAllGather of [n_frames][n_loc][n_cells] per device (the single gather of north_star)
-//     ragged blocks : one ncclGroup of send/recv pairs (block of frame f, device r -> its place in frame f on the root)
-// then the root transposes into mono8 images and copies them to the caller's host buffer.
+// collective per call GATHERS the blocks on device 0 (the root) -- one ncclGroup of send / recv pairs along
+// rr_multi_plan: one piece per device for equal blocks, one per device and frame for ragged ones; nobody but the
+// root receives anything -- then the root transposes into mono8 images and copies them to the caller's host buffer.
+// Calls are PIPELINED (round 4): rr_multi_simulate_batch_async enqueues a batch on one of RR_MULTI_SLOTS (4) slots --
+// own stream + block buffer per device, own receive / image buffers on the root -- and returns; rr_multi_wait is the
+// consumer's fence.  The render of batch k+1 overlaps the collective, transpose and D2H copy of batch k, like the
+// slots of dist.py's step loop.  Per-batch error bits travel to page-locked host words (rr_peek_error_bits_async), so
+// no call drains a device unless something failed.
 // RCCL is loaded at run time (librccl.so.1): the library itself has no link-time dependency on it and
 // rr_create_multi() fails with a clear message where it is missing.  Built on the public entry points of
 // radarays_mi355.h only.
@@ -16,6 +20,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -33,7 +38,6 @@ struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -44,7 +48,7 @@ struct Rccl {
         for (const char* n : { "librccl.so.1", "librccl.so" }) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
         if (!lib) { err = "rr_create_multi: librccl.so.1 not found (RCCL is needed for more than one device)"; return false; }
 #define RR_SYM(f) f = (decltype(f))dlsym(lib, "nccl" #f); if (!f) { err = "rr_create_multi: librccl lacks nccl" #f; return false; }
-        RR_SYM(CommInitAll) RR_SYM(CommDestroy) RR_SYM(AllGather) RR_SYM(Send) RR_SYM(Recv) RR_SYM(GroupStart) RR_SYM(GroupEnd) RR_SYM(GetErrorString)
+        RR_SYM(CommInitAll) RR_SYM(CommDestroy) RR_SYM(Send) RR_SYM(Recv) RR_SYM(GroupStart) RR_SYM(GroupEnd) RR_SYM(GetErrorString)
 #undef RR_SYM
         return true;
     }
@@ -67,14 +71,27 @@ struct Buf {
 
 }  // namespace
 
+// one batch in flight: its own stream and block buffer on every device, the root's receive / image buffers, the host
+// words the devices' error bits arrive in
+struct MultiSlot {
+    std::vector<hipStream_t> streams;     // per device
+    std::vector<Buf<uint8_t>> block;      // per device: [n_frames][n_loc_i][n_cells]
+    std::vector<hipEvent_t> ev_block;     // per device: block rendered (loopback: the root's copies wait for it)
+    Buf<uint8_t> gathered;                // root: what the collective delivers
+    Buf<uint8_t> d_imgs;                  // root: [n_frames][n_cells][n_angles]
+    hipEvent_t ev_done = nullptr;         // root: images in the caller's buffer
+    uint32_t* h_bits = nullptr;           // page-locked [n_devices]: rr_peek_error_bits_async
+    const void* dst = nullptr;            // the caller's buffer of the batch in flight
+    bool pending = false;
+    bool owns_streams = true;             // one device: twice as many records as streams (see rr_create_multi)
+};
+
 struct rr_multi {
     std::vector<int> devices;
     std::vector<rr_ctx*> ctx;
-    std::vector<hipStream_t> streams;
     std::vector<ncclComm_t> comms;
-    std::vector<Buf<uint8_t>> block;      // per device: [n_frames][n_loc_i][n_cells]
-    std::vector<Buf<uint8_t>> gathered;   // per device (all-gather) / root only (send/recv)
-    Buf<uint8_t> d_imgs;                  // root: [n_frames][n_cells][n_angles]
+    std::vector<MultiSlot> slots;         // batches in flight (RR_MULTI_SLOTS, default 4)
+    size_t next_slot = 0;
     rr_config cfg;
     bool have_cfg = false;
     bool loopback = false;                // see rr_create_multi
@@ -117,13 +134,30 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
         rr_ctx* c = rr_create(devices[i]);
         if (!c) { g_multi_create_error = std::string("rr_create_multi: ") + rr_last_error(nullptr); rr_destroy_multi(m); return nullptr; }
         m->ctx.push_back(c);
-        hipStream_t s = nullptr;
-        if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
-            g_multi_create_error = "rr_create_multi: stream creation failed"; rr_destroy_multi(m); return nullptr;
-        }
-        m->streams.push_back(s);
     }
-    m->block.resize((size_t)n_devices); m->gathered.resize((size_t)n_devices);
+    // batches in flight: 4 streams per device = its 4 hardware queues, the measured optimum of the one-GPU step loop
+    int n_slots = getenv("RR_MULTI_SLOTS") ? atoi(getenv("RR_MULTI_SLOTS")) : 4;
+    n_slots = std::max(1, std::min(n_slots, 8));
+    // One device: a batch owns no buffers here (its images wait on the ctx's frame lane until the lane's next batch carries
+    // them out), so the records outnumber the streams two to one -- a call then waits for the batch EIGHT back, not for
+    // the one whose deferred images its own launches are about to carry (that wait would force the plain copy every time)
+    m->slots.resize((size_t)(n_devices == 1 ? 2 * n_slots : n_slots));
+    for (size_t si = 0; si < m->slots.size(); si++) {
+        MultiSlot& S = m->slots[si];
+        S.block.resize((size_t)n_devices);
+        S.streams.assign((size_t)n_devices, nullptr); S.ev_block.assign((size_t)n_devices, nullptr);
+        bool ok = true;
+        S.owns_streams = si < (size_t)n_slots;
+        if (!S.owns_streams) S.streams = m->slots[si - (size_t)n_slots].streams;
+        for (int i = 0; i < n_devices && ok; i++)
+            ok = hipSetDevice(devices[i]) == hipSuccess &&
+                 (!S.owns_streams || hipStreamCreateWithFlags(&S.streams[(size_t)i], hipStreamNonBlocking) == hipSuccess) &&
+                 hipEventCreateWithFlags(&S.ev_block[(size_t)i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipSetDevice(devices[0]) == hipSuccess && hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming) == hipSuccess &&
+             hipHostMalloc((void**)&S.h_bits, sizeof(uint32_t) * (size_t)n_devices, hipHostMallocDefault) == hipSuccess;
+        if (!ok) { g_multi_create_error = "rr_create_multi: stream / event creation failed"; rr_destroy_multi(m); return nullptr; }
+        for (int i = 0; i < n_devices; i++) S.h_bits[i] = 0;
+    }
     if (n_devices > 1 && !loopback) {
         // the communicator is owned here: one rank per device of this process
         if (!g_rccl.load(g_multi_create_error)) { rr_destroy_multi(m); return nullptr; }
@@ -137,16 +171,21 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
 void rr_destroy_multi(rr_multi* m)
 {
     if (!m) return;
-    for (size_t i = 0; i < m->ctx.size(); i++) {
-        (void)hipSetDevice(m->devices[i]);
-        (void)hipDeviceSynchronize();
-        if (i < m->comms.size() && m->comms[i]) g_rccl.CommDestroy(m->comms[i]);
-        if (i < m->block.size()) m->block[i].release();
-        if (i < m->gathered.size()) m->gathered[i].release();
-        if (i == 0) m->d_imgs.release();
-        if (i < m->streams.size() && m->streams[i]) (void)hipStreamDestroy(m->streams[i]);
-        rr_destroy(m->ctx[i]);
+    for (size_t i = 0; i < m->ctx.size(); i++) { (void)hipSetDevice(m->devices[i]); (void)hipDeviceSynchronize(); }
+    for (size_t i = 0; i < m->comms.size(); i++) if (m->comms[i]) g_rccl.CommDestroy(m->comms[i]);
+    for (MultiSlot& S : m->slots) {
+        for (size_t i = 0; i < S.streams.size(); i++) {
+            (void)hipSetDevice(m->devices[i]);
+            if (i < S.block.size()) S.block[i].release();
+            if (S.ev_block[i]) (void)hipEventDestroy(S.ev_block[i]);
+            if (S.owns_streams && S.streams[i]) (void)hipStreamDestroy(S.streams[i]);
+        }
+        (void)hipSetDevice(m->devices[0]);
+        S.gathered.release(); S.d_imgs.release();
+        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+        if (S.h_bits) (void)hipHostFree(S.h_bits);
     }
+    for (size_t i = 0; i < m->ctx.size(); i++) rr_destroy(m->ctx[i]);
     delete m;
 }
 
@@ -239,7 +278,70 @@ int rr_multi_plan(int n_angles, int n_cells, int n_devices, int n_frames, int* e
 }
 
 // ---- frames ------------------------------------------------------------------------------------------------
-int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8_t* out_imgs_u8)
+namespace {
+
+// after an error: nothing of this object may still be in flight when the caller gets the code back (a late D2H copy
+// into a buffer the caller frees on error; sticky error bits that would fail the next, healthy call) -- every device is
+// drained, its error bits are read and cleared, every slot is free again.  Returns the first error a device reports.
+int drain_all(rr_multi* m, std::string* first_msg)
+{
+    int first = 0;
+    for (size_t i = 0; i < m->ctx.size(); i++) { (void)hipSetDevice(m->devices[i]); (void)hipDeviceSynchronize(); }
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        const int rc = rr_synchronize(m->ctx[i], nullptr);
+        if (rc && !first) { first = rc; if (first_msg) *first_msg = std::string("device ") + std::to_string(m->devices[i]) + ": " + rr_last_error(m->ctx[i]); }
+    }
+    for (MultiSlot& S : m->slots) { S.pending = false; S.dst = nullptr; for (size_t i = 0; i < m->ctx.size(); i++) S.h_bits[i] = 0; }
+    return first;
+}
+
+// a launch-time failure: keep ITS message, but hand the object back drained
+int fail_drained(rr_multi* m, int code, const std::string& msg)
+{
+    (void)drain_all(m, nullptr);
+    return mfail(m, code, msg);
+}
+
+int wait_slot(rr_multi* m, MultiSlot& S)
+{
+    if (!S.pending) return 0;
+    const int n = (int)m->ctx.size();
+    hipError_t e = hipSetDevice(m->devices[0]);
+    if (e == hipSuccess && n == 1) {
+        // the image may still sit on its frame lane (rr_simulate_batch_host_async defers the copy): deliver it
+        if (rr_wait_host(m->ctx[0], S.dst)) return fail_drained(m, -100, std::string("device ") + std::to_string(m->devices[0]) + ": " + rr_last_error(m->ctx[0]));
+    }
+    if (e == hipSuccess) e = hipEventSynchronize(S.ev_done);
+    if (e != hipSuccess) return fail_drained(m, -100, std::string("rr_multi_wait: ") + hipGetErrorString(e));
+    S.pending = false; S.dst = nullptr;
+    // the root's stream is ordered behind every device's block (collective / events), each block behind its error bits
+    uint32_t bits = 0;
+    for (int i = 0; i < n; i++) bits |= S.h_bits[i];
+    if (bits) {
+        std::string msg;
+        const int rc = drain_all(m, &msg);
+        return mfail(m, rc ? rc : ((bits & 1u) ? -7 : -8), rc ? msg : "a device reported an overflow / bad id");
+    }
+    return 0;
+}
+
+}  // namespace
+
+int rr_multi_wait(rr_multi* m, const void* h_imgs_u8)
+{
+    if (!m) return -1;
+    // oldest first, so that an error is reported for the batch that caused it
+    int first = 0;
+    for (size_t k = 0; k < m->slots.size(); k++) {
+        MultiSlot& S = m->slots[(m->next_slot + k) % m->slots.size()];
+        if (!S.pending || (h_imgs_u8 && S.dst != h_imgs_u8)) continue;
+        const int rc = wait_slot(m, S);
+        if (rc) { if (!first) first = rc; break; }       // (a failed wait drained everything)
+    }
+    return first;
+}
+
+int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames, uint8_t* out_imgs_u8)
 {
     if (!m) return -1;
     if (!m->have_cfg) return mfail(m, -2, "rr_multi_set_config has not been called");
@@ -247,79 +349,98 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
     if (n_frames < 1 || n_frames > RR_MAX_BATCH) return mfail(m, -3, "rr_multi_simulate_batch: n_frames must be 1..64");
     const int n = (int)m->ctx.size();
     const int A = m->cfg.n_angles; const size_t C = (size_t)m->cfg.n_cells;
+    MultiSlot& S = m->slots[m->next_slot];
+    m->next_slot = (m->next_slot + 1) % m->slots.size();
+    { const int rc = wait_slot(m, S); if (rc) return rc; }        // the batch that used this slot's buffers last
+    const auto dev_msg = [&](int i) { return std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rr_last_error(m->ctx[(size_t)i]); };
+    if (n == 1) {
+        // one device: no collective; the images take the ctx's own host delivery (deferred, trickled out by the next
+        // batch's trace launches: within 1 % of leaving them in HBM)
+        RRM_HIP(m, hipSetDevice(m->devices[0]));
+        int rc = rr_simulate_batch_host_async(m->ctx[0], poses, n_frames, out_imgs_u8, S.streams[0]);
+        if (rc) return fail_drained(m, rc, dev_msg(0));
+        rc = rr_peek_error_bits_async(m->ctx[0], &S.h_bits[0], S.streams[0]);
+        if (rc) return fail_drained(m, rc, dev_msg(0));
+        hipError_t e = hipEventRecord(S.ev_done, S.streams[0]);
+        if (e != hipSuccess) return fail_drained(m, -100, std::string("hipEventRecord: ") + hipGetErrorString(e));
+        S.pending = true; S.dst = out_imgs_u8;
+        return 0;
+    }
+#define RRM_TRY_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_drained(m, -100, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define RRM_TRY_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != 0) return fail_drained(m, -101, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); } while (0)
     std::vector<int> b((size_t)n), e((size_t)n);
     bool equal = true;
     for (int i = 0; i < n; i++) { rr_partition(A, n, i, &b[(size_t)i], &e[(size_t)i]); equal = equal && (e[(size_t)i] - b[(size_t)i]) == (e[0] - b[0]); }
     // 1. every device renders its block of all frames (one set of launches each, all devices concurrently)
     for (int i = 0; i < n; i++) {
         const size_t nl = (size_t)(e[(size_t)i] - b[(size_t)i]);
-        RRM_HIP(m, hipSetDevice(m->devices[(size_t)i]));
-        RRM_HIP(m, m->block[(size_t)i].ensure(std::max<size_t>(1, (size_t)n_frames * nl * C)));
-        if (nl == 0) continue;
-        rr_ctx* c = m->ctx[(size_t)i];
-        const int rc = rr_simulate_batch_columns_device(c, poses, n_frames, b[(size_t)i], e[(size_t)i], m->block[(size_t)i].p, m->streams[(size_t)i]);
-        if (rc) return mfail(m, rc, std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rr_last_error(c));
-    }
-    // 2. ONE collective: the blocks meet on the root
-    const uint8_t* d_cols = nullptr; int n_loc = A; size_t block_stride = (size_t)A * C, frame_stride = (size_t)A * C;
-    if (n == 1) {
-        d_cols = m->block[0].p;                            // [n_frames][A][C]
-    } else if (equal) {
-        const size_t nl = (size_t)(e[0] - b[0]), per = (size_t)n_frames * nl * C;
-        for (int i = 0; i < n; i++) { RRM_HIP(m, hipSetDevice(m->devices[(size_t)i])); RRM_HIP(m, m->gathered[(size_t)i].ensure((size_t)n * per)); }
-        if (m->loopback) {
-            // what the all-gather leaves on the root: block r at r * per
-            for (int i = 0; i < n; i++) RRM_HIP(m, hipStreamSynchronize(m->streams[(size_t)i]));
-            for (int i = 0; i < n; i++)
-                RRM_HIP(m, hipMemcpyAsync(m->gathered[0].p + (size_t)i * per, m->block[(size_t)i].p, per, hipMemcpyDeviceToDevice, m->streams[0]));
-        } else {
-        RRM_NCCL(m, g_rccl.GroupStart());
-        for (int i = 0; i < n; i++)
-            RRM_NCCL(m, g_rccl.AllGather(m->block[(size_t)i].p, m->gathered[(size_t)i].p, per, kNcclUint8, m->comms[(size_t)i], m->streams[(size_t)i]));
-        RRM_NCCL(m, g_rccl.GroupEnd());
+        RRM_TRY_HIP(hipSetDevice(m->devices[(size_t)i]));
+        RRM_TRY_HIP(S.block[(size_t)i].ensure(std::max<size_t>(1, (size_t)n_frames * nl * C)));
+        S.h_bits[i] = 0;
+        if (nl > 0) {
+            rr_ctx* c = m->ctx[(size_t)i];
+            int rc = rr_simulate_batch_columns_device(c, poses, n_frames, b[(size_t)i], e[(size_t)i], S.block[(size_t)i].p, S.streams[(size_t)i]);
+            if (!rc) rc = rr_peek_error_bits_async(c, &S.h_bits[i], S.streams[(size_t)i]);
+            if (rc) return fail_drained(m, rc, dev_msg(i));
         }
-        d_cols = m->gathered[0].p;                         // [device][n_frames][nl][C]
+        RRM_TRY_HIP(hipEventRecord(S.ev_block[(size_t)i], S.streams[(size_t)i]));
+    }
+    // 2. ONE collective: a GATHER to the root (device 0), nobody else receives anything.  RCCL has no plain gather in
+    //    every version, so it is one group of send / recv pairs along rr_multi_plan: equal blocks travel as one piece
+    //    per device into the layout [device][frame][n_loc][n_cells], ragged ones frame by frame into
+    //    [frame][n_angles][n_cells]; the root's own block is a device-to-device copy on its stream
+    RRM_TRY_HIP(hipSetDevice(m->devices[0]));
+    const uint8_t* d_cols = nullptr; int n_loc = A; size_t block_stride = (size_t)A * C, frame_stride = (size_t)A * C;
+    struct Piece { int dev; size_t so, ro, bytes; };
+    std::vector<Piece> pieces;
+    if (equal) {
+        const size_t nl = (size_t)(e[0] - b[0]), per = (size_t)n_frames * nl * C;
+        RRM_TRY_HIP(S.gathered.ensure((size_t)n * per));
+        for (int i = 0; i < n; i++) pieces.push_back({ i, 0, (size_t)i * per, per });
         n_loc = (int)nl; block_stride = per; frame_stride = nl * C;
     } else {
-        RRM_HIP(m, hipSetDevice(m->devices[0]));
-        RRM_HIP(m, m->gathered[0].ensure((size_t)n_frames * A * C));
+        RRM_TRY_HIP(S.gathered.ensure((size_t)n_frames * A * C));
         std::vector<size_t> so((size_t)n * n_frames), ro((size_t)n * n_frames), pb((size_t)n * n_frames);
         (void)rr_multi_plan(A, (int)C, n, n_frames, nullptr, nullptr, so.data(), ro.data(), pb.data());
-        if (m->loopback) {
-            for (int i = 0; i < n; i++) RRM_HIP(m, hipStreamSynchronize(m->streams[(size_t)i]));
-            for (int i = 0; i < n; i++)
-                for (int f = 0; f < n_frames; f++) {
-                    const size_t k = (size_t)i * n_frames + f;
-                    if (pb[k] == 0) continue;
-                    RRM_HIP(m, hipMemcpyAsync(m->gathered[0].p + ro[k], m->block[(size_t)i].p + so[k], pb[k], hipMemcpyDeviceToDevice, m->streams[0]));
-                }
-        } else {
-        RRM_NCCL(m, g_rccl.GroupStart());
-        for (int i = 0; i < n; i++)
-            for (int f = 0; f < n_frames; f++) {
-                const size_t k = (size_t)i * n_frames + f;
-                if (pb[k] == 0) continue;
-                RRM_NCCL(m, g_rccl.Send(m->block[(size_t)i].p + so[k], pb[k], kNcclUint8, 0, m->comms[(size_t)i], m->streams[(size_t)i]));
-                RRM_NCCL(m, g_rccl.Recv(m->gathered[0].p + ro[k], pb[k], kNcclUint8, i, m->comms[0], m->streams[0]));
-            }
-        RRM_NCCL(m, g_rccl.GroupEnd());
+        for (int i = 0; i < n; i++) for (int f = 0; f < n_frames; f++) {
+            const size_t k = (size_t)i * n_frames + f;
+            if (pb[k]) pieces.push_back({ i, so[k], ro[k], pb[k] });
         }
-        d_cols = m->gathered[0].p;                         // [n_frames][A][C]
+    }
+    d_cols = S.gathered.p;
+    for (const Piece& p : pieces)          // the root's own pieces (and, in loopback, everybody's): plain copies on the root's stream
+        if (p.dev == 0 || m->loopback) {
+            if (p.dev != 0) RRM_TRY_HIP(hipStreamWaitEvent(S.streams[0], S.ev_block[(size_t)p.dev], 0));
+            RRM_TRY_HIP(hipMemcpyAsync(S.gathered.p + p.ro, S.block[(size_t)p.dev].p + p.so, p.bytes, hipMemcpyDeviceToDevice, S.streams[0]));
+        }
+    if (!m->loopback) {
+        RRM_TRY_NCCL(g_rccl.GroupStart());
+        for (const Piece& p : pieces) {
+            if (p.dev == 0) continue;
+            RRM_TRY_NCCL(g_rccl.Send(S.block[(size_t)p.dev].p + p.so, p.bytes, kNcclUint8, 0, m->comms[(size_t)p.dev], S.streams[(size_t)p.dev]));
+            RRM_TRY_NCCL(g_rccl.Recv(S.gathered.p + p.ro, p.bytes, kNcclUint8, p.dev, m->comms[0], S.streams[0]));
+        }
+        RRM_TRY_NCCL(g_rccl.GroupEnd());
     }
     // 3. root: transpose into mono8 images, copy to the caller's host buffer
-    RRM_HIP(m, hipSetDevice(m->devices[0]));
+    RRM_TRY_HIP(hipSetDevice(m->devices[0]));
     const size_t bytes = (size_t)n_frames * C * A;
-    RRM_HIP(m, m->d_imgs.ensure(bytes));
-    int rc = rr_assemble_frames_device(m->ctx[0], d_cols, n_loc, block_stride, n_frames, frame_stride, m->d_imgs.p, m->streams[0]);
-    if (rc) return mfail(m, rc, std::string("root: ") + rr_last_error(m->ctx[0]));
-    RRM_HIP(m, hipMemcpyAsync(out_imgs_u8, m->d_imgs.p, bytes, hipMemcpyDeviceToHost, m->streams[0]));
-    // 4. drain; per-device error bits (queue overflow / bad ids) surface here
-    for (int i = n - 1; i >= 0; i--) {
-        rr_ctx* c = m->ctx[(size_t)i];
-        rc = rr_synchronize(c, m->streams[(size_t)i]);
-        if (rc) return mfail(m, rc, std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rr_last_error(c));
-    }
+    RRM_TRY_HIP(S.d_imgs.ensure(bytes));
+    { const int rc = rr_assemble_frames_device(m->ctx[0], d_cols, n_loc, block_stride, n_frames, frame_stride, S.d_imgs.p, S.streams[0]);
+      if (rc) return fail_drained(m, rc, std::string("root: ") + rr_last_error(m->ctx[0])); }
+    RRM_TRY_HIP(hipMemcpyAsync(out_imgs_u8, S.d_imgs.p, bytes, hipMemcpyDeviceToHost, S.streams[0]));
+    RRM_TRY_HIP(hipEventRecord(S.ev_done, S.streams[0]));
+#undef RRM_TRY_HIP
+#undef RRM_TRY_NCCL
+    S.pending = true; S.dst = out_imgs_u8;
     return 0;
+}
+
+int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8_t* out_imgs_u8)
+{
+    const int rc = rr_multi_simulate_batch_async(m, poses, n_frames, out_imgs_u8);
+    if (rc) return rc;
+    return rr_multi_wait(m, out_imgs_u8);
 }
 
 int rr_multi_simulate(rr_multi* m, const float pose_qxyzw_t[7], uint8_t* out_u8)

@@ -25,6 +25,7 @@ SYMBOLS = [
     "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_ctx",
     "rr_multi_set_mesh", "rr_multi_set_mesh_gpu", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
     "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
+    "rr_multi_simulate_batch_async", "rr_multi_wait", "rr_peek_error_bits_async",
 ]
 
 
@@ -152,6 +153,9 @@ def lib():
     L.rr_multi_set_motion_poses.argtypes = [vp, vp, C.c_size_t]
     L.rr_multi_simulate.argtypes = [vp, vp, vp]
     L.rr_multi_simulate_batch.argtypes = [vp, vp, C.c_int, vp]
+    L.rr_multi_simulate_batch_async.argtypes = [vp, vp, C.c_int, vp]
+    L.rr_multi_wait.argtypes = [vp, vp]
+    L.rr_peek_error_bits_async.argtypes = [vp, vp, vp]
     for n in SYMBOLS:
         getattr(L, n)
     _LIB = L
@@ -488,3 +492,12 @@ class MultiContext:
 
     def simulate(self, pose):
         return self.simulate_batch([pose])[0]
+
+    def simulate_batch_async(self, poses, h_imgs_ptr):
+        """Pipelined: enqueue the batch, images [n][n_cells][n_angles] arrive at h_imgs_ptr (page-locked: HostImages);
+        complete after wait(h_imgs_ptr)."""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ck(self._L.rr_multi_simulate_batch_async(self._h, p.ctypes.data, len(p), h_imgs_ptr))
+
+    def wait(self, h_imgs_ptr=None):
+        self._ck(self._L.rr_multi_wait(self._h, h_imgs_ptr))

@@ -2,14 +2,21 @@
 // lanes and of the frame-batch entry points, images resident in HBM.
 //   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tools/cpp_bench.cpp \
 //       -o /tmp/cpp_bench -L radarays_ros_amd -lradarays_mi355 -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/radarays_ros_amd
-//   /tmp/cpp_bench scene.bin [frames] [batch]      (scene.bin as written by tests/test_cpp_host.py: write_scene)
+//   /tmp/cpp_bench scene.bin [frames] [batch] [mode]   (scene.bin as written by tests/test_cpp_host.py: write_scene)
+//   mode: (none) device-resident rates | sync: rr_simulate one frame at a time (the reference's call shape) |
+//         multi: rr_multi_simulate_batch_async on devices {0} against rr_simulate_batch_host_async (host-resident rates) |
+//         graph: the launch chain of one frame captured in a hipGraph against the same chain launched kernel by kernel
+//                (run with RR_LANES=1: the single-lane route of rr_simulate_device puts every launch on the caller's stream)
 #include <hip/hip_runtime_api.h>
 #include <radarays_mi355.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
+#include <string>
 #include <vector>
 
 template <typename T> static std::vector<T> rd(std::ifstream& f)
@@ -20,8 +27,9 @@ template <typename T> static std::vector<T> rd(std::ifstream& f)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s scene.bin [frames] [batch]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s scene.bin [frames] [batch] [sync|multi|graph]\n", argv[0]); return 2; }
     const int frames = argc > 2 ? atoi(argv[2]) : 2000, batch = argc > 3 ? atoi(argv[3]) : 4;
+    const std::string mode = argc > 4 ? argv[4] : "";
     std::ifstream f(argv[1], std::ios::binary);
     auto verts = rd<float>(f); auto faces = rd<uint32_t>(f); auto fobj = rd<uint32_t>(f);
     auto mats = rd<float>(f); auto objmat = rd<int32_t>(f); auto beams = rd<float>(f); auto pose = rd<float>(f); auto cfgv = rd<double>(f);
@@ -42,6 +50,93 @@ int main(int argc, char** argv)
     hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     std::vector<float> poses(7 * 32);
     for (int k = 0; k < 32; k++) { for (int j = 0; j < 7; j++) poses[7 * k + j] = pose[j]; poses[7 * k + 4] += 0.05f * k; }
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    if (mode == "sync") {
+        // the reference's call shape: one synchronous simulate() per frame, image in (pageable) host memory
+        std::vector<uint8_t> img(npx); rr_stats st;
+        for (int k = 0; k < 10; k++) CK(rr_simulate(c, &poses[7 * (k % 16)], 0, cfg.n_angles, img.data(), nullptr, &st));
+        std::vector<double> ts;
+        for (int k = 0; k < frames; k++) {
+            auto a = clk::now(); CK(rr_simulate(c, &poses[7 * (k % 16)], 0, cfg.n_angles, img.data(), nullptr, &st)); ts.push_back(secs(a, clk::now()));
+        }
+        std::sort(ts.begin(), ts.end());
+        std::printf("rr_simulate (sync, host image, stats): median %.3f ms  p10 %.3f  p90 %.3f  (%llu wave-passes)\n", 1e3 * ts[ts.size() / 2],
+                    1e3 * ts[ts.size() / 10], 1e3 * ts[ts.size() * 9 / 10], (unsigned long long)st.wave_passes);
+        rr_destroy(c); return 0;
+    }
+    if (mode == "graph") {
+        hipStream_t gs; hipStreamCreateWithFlags(&gs, hipStreamNonBlocking);
+        for (int k = 0; k < 10; k++) CK(rr_simulate_device(c, &poses[0], d_img, gs));
+        hipStreamSynchronize(gs);
+        std::vector<double> ts;
+        for (int k = 0; k < frames; k++) { auto a = clk::now(); CK(rr_simulate_device(c, &poses[0], d_img, gs)); hipStreamSynchronize(gs); ts.push_back(secs(a, clk::now())); }
+        std::sort(ts.begin(), ts.end());
+        std::printf("kernel by kernel : median %.3f ms per frame (p10 %.3f)\n", 1e3 * ts[ts.size() / 2], 1e3 * ts[ts.size() / 10]);
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        hipError_t e = hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { std::printf("capture refused: %s\n", hipGetErrorString(e)); return 0; }
+        const int rc = rr_simulate_device(c, &poses[0], d_img, gs);
+        e = hipStreamEndCapture(gs, &g);
+        if (rc || e != hipSuccess || !g) { std::printf("capture failed: rc %d (%s), %s\n", rc, rr_last_error(c), hipGetErrorString(e)); return 0; }
+        size_t nn = 0; hipGraphGetNodes(g, nullptr, &nn);
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (e != hipSuccess) { std::printf("instantiate failed: %s\n", hipGetErrorString(e)); return 0; }
+        for (int k = 0; k < 10; k++) hipGraphLaunch(ge, gs);
+        hipStreamSynchronize(gs);
+        ts.clear();
+        for (int k = 0; k < frames; k++) { auto a = clk::now(); hipGraphLaunch(ge, gs); hipStreamSynchronize(gs); ts.push_back(secs(a, clk::now())); }
+        std::sort(ts.begin(), ts.end());
+        std::printf("hipGraph (%zu nodes): median %.3f ms per frame (p10 %.3f)\n", nn, 1e3 * ts[ts.size() / 2], 1e3 * ts[ts.size() / 10]);
+        rr_destroy(c); return 0;
+    }
+    if (mode == "multi") {
+        // host-resident rates: the C++ drop-in's route (rr_multi over {0}) against the ctx's own host delivery
+        const int ring = 8, steps = frames / batch;
+        std::vector<uint8_t*> host(ring);
+        for (auto& h : host) { h = (uint8_t*)rr_host_alloc((size_t)batch * npx); if (!h) return 4; }
+        hipStream_t st4[4]; for (auto& x : st4) hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
+        auto run_ctx = [&](int n) -> int {
+            for (int k = 0; k < n; k++) {
+                uint8_t* h = host[k % ring];
+                if (rr_wait_host(c, h)) return 1;
+                if (rr_simulate_batch_host_async(c, &poses[7 * (k % (32 - batch + 1))], batch, h, st4[k % 4])) return 1;
+            }
+            return rr_wait_host(c, nullptr) || rr_synchronize(c, nullptr);
+        };
+        if (run_ctx(64)) { std::fprintf(stderr, "%s\n", rr_last_error(c)); return 1; }
+        auto a = clk::now();
+        if (run_ctx(steps)) { std::fprintf(stderr, "%s\n", rr_last_error(c)); return 1; }
+        const double t_ctx = secs(a, clk::now());
+        std::printf("rr_simulate_batch_host_async, %d poses per call, 4 streams: %.0f images/s host-resident\n", batch, steps * batch / t_ctx);
+        rr_destroy(c);
+        const int dev0 = 0;
+        rr_multi* m = rr_create_multi(&dev0, 1);
+        if (!m) { std::fprintf(stderr, "%s\n", rr_multi_last_error(nullptr)); return 6; }
+#define MK(x) do { if ((x) != 0) { std::fprintf(stderr, "%s: %s\n", #x, rr_multi_last_error(m)); return 1; } } while (0)
+        MK(rr_multi_set_mesh(m, verts.data(), verts.size() / 3, faces.data(), faces.size() / 3, fobj.data()));
+        MK(rr_multi_set_materials(m, (const rr_material*)mats.data(), mats.size() / 4, objmat.data(), objmat.size(), 0));
+        MK(rr_multi_set_config(m, &cfg));
+        MK(rr_multi_set_beam_samples(m, beams.data(), beams.size() / 3));
+        MK(rr_multi_set_noise_offsets(m, rnd.data(), rnd.size()));
+        auto run_multi = [&](int n) -> int {
+            for (int k = 0; k < n; k++) {
+                uint8_t* h = host[k % ring];
+                if (rr_multi_wait(m, h)) return 1;
+                if (rr_multi_simulate_batch_async(m, &poses[7 * (k % (32 - batch + 1))], batch, h)) return 1;
+            }
+            return rr_multi_wait(m, nullptr);
+        };
+        MK(run_multi(64));
+        a = clk::now();
+        MK(run_multi(steps));
+        const double t_m = secs(a, clk::now());
+        std::printf("rr_multi_simulate_batch_async {0}, %d poses per call: %.0f images/s host-resident = %.1f %% of the ctx route\n", batch,
+                    steps * batch / t_m, 100.0 * t_ctx / t_m);
+        rr_destroy_multi(m);
+        for (auto h : host) rr_host_free(h);
+        return 0;
+    }
     // (1) one frame per call, pipelined over the context's frame lanes
     for (int k = 0; k < 20; k++) CK(rr_simulate_device(c, &poses[7 * (k % 16)], d_img, s));
     hipStreamSynchronize(s);
