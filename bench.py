@@ -84,6 +84,17 @@ def pct(v, q):
     return float(v[min(len(v) - 1, int(q * len(v)))]) if len(v) else 0.0
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the sources that decide what the kernels execute: the kernels, the device layout,
+    the tree builders.  profiles/make_counters.py stores it beside the PMC counters."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rr_kernels.hip", "rr_device.h", "rr_bvh.h", "rr_bvh.cpp", "rr_lbvh.hip"):
+        with open(os.path.join(ROOT, "radarays_ros_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def visible_gpus():
     """Number of GPUs this process could use, WITHOUT initialising the HIP runtime: the KFD topology in sysfs
     (a node with SIMDs is a GPU), narrowed by HIP_/ROCR_VISIBLE_DEVICES; torch.cuda.device_count() -- which does not
@@ -142,6 +153,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--ambient-noise", type=int, default=2)
     ap.add_argument("--strong", action="store_true", help="N>1: one frame per batch + all-gather")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="go through the torch.distributed.run child even for N = 1 (exercises the launcher path on a one-GPU box)")
     ap.add_argument("--force-slots", action="store_true", help="run the N>1 step loop (with its collective) on one rank (debug)")
     ap.add_argument("--slots", type=int, default=4, help="batches in flight (streams + buffer sets); RR_LANES must be >= slots")
     ap.add_argument("--frames-per-rank", type=int, default=8,
@@ -152,11 +165,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and (args.gpus > 1 or args.self_launch):
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything in this
+        # process touches the GPU (the parent only counts devices and waits for the child)
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything in this
-            # process touches the GPU (the parent only counts devices and waits for the child)
-            raise SystemExit(self_launch(args.gpus))
         args.gpus = world
 
     import torch
@@ -243,6 +256,7 @@ def main():
     shard.step([poses[f % len(poses)] for f in range(fpb)], None)
     torch.cuda.synchronize()
     st2 = ctx.stats()
+    shape = ctx.traversal_shape()
     ctx.set_stats_mode(False)
     # every kernel alone on the GPU (one batch at a time, nothing else in flight): which kernel takes the most
     # time, and its own speed -- as opposed to its duration while several batches share the chip below
@@ -296,7 +310,7 @@ def main():
         wave_passes_batch = wave_passes_batch_rank
 
     # ---- N = 1 extras: the image delivered to host memory; one pose per launch set ---------------------------
-    host_res = single = None
+    host_res = single = sync1 = proxy = None
     if world == 1 and not args.no_extras and not args.force_slots:
         npx = cfg.n_cells * params.N_ANGLES
         F = args.frames_per_rank
@@ -342,6 +356,43 @@ def main():
                   "ms_per_image": round(1e3 * (ts1 - ts0) / n1, 4), "images": n1,
                   "what": "one pose per set of launches, %d in flight on %d streams, image left in HBM" % (args.slots, args.slots)}
         one.close()
+        # the reference's own call shape (radar_simulator.cpp:197-212): ONE synchronous simulate() per frame, image in host memory
+        img = np.zeros((cfg.n_cells, params.N_ANGLES), np.uint8)
+        for k in range(8):
+            ctx.simulate_into(poses[k % len(poses)], img)
+        lat = []
+        for k in range(60):
+            tq = time.perf_counter()
+            ctx.simulate_into(poses[k % len(poses)], img)
+            lat.append(1e3 * (time.perf_counter() - tq))
+        sync1 = {"ms_per_frame": round(pct(lat, 0.5), 4), "p10": round(pct(lat, 0.1), 4), "p90": round(pct(lat, 0.9), 4),
+                 "images_per_s": round(1e3 / pct(lat, 0.5), 1), "frames": len(lat),
+                 "what": "rr_simulate: one pose, nothing else in flight, wall time of the call including the D2H copy of the mono8 image "
+                         "into pageable host memory (the latency a ROS node calling Radar::simulate() per frame sees)"}
+        # strong-scaling proxy on ONE GPU: a block of 400/N azimuth columns alone on the chip against the whole frame -- what
+        # sharding ONE frame N ways can win at best (the collective and the transpose still to be added)
+        blk = torch.zeros((params.N_ANGLES, cfg.n_cells), dtype=torch.uint8, device=dev)
+        s1 = torch.cuda.Stream(device=dev)
+
+        def block_ms(b, e, n=40):
+            ts = []
+            for k in range(n + 6):
+                torch.cuda.synchronize(); tq = time.perf_counter()
+                ctx.simulate_columns_device(poses[k % len(poses)], b, e, blk.data_ptr(), None, s1.cuda_stream); s1.synchronize()
+                if k >= 6:
+                    ts.append(1e3 * (time.perf_counter() - tq))
+            return pct(ts, 0.5)
+        t_full = block_ms(0, params.N_ANGLES)
+        proxy = {"ms_400_columns": round(t_full, 4)}
+        for n_sh in (2, 4, 8):
+            b, e = native.partition(params.N_ANGLES, n_sh, n_sh // 2)
+            t_b = block_ms(b, e)
+            proxy["ms_%d_columns" % (e - b)] = round(t_b, 4)
+            proxy["speedup_bound_%d_gpus" % n_sh] = round(t_full / t_b, 3)
+            proxy["strong_ceiling_%d" % n_sh] = round(t_full / (n_sh * t_b), 4)
+        proxy["what"] = ("one frame's kernel chain for a block of 400/N columns alone on the GPU vs all 400: an upper bound of the "
+                         "strong-scaling speed-up of ONE frame on N GPUs (efficiency = strong_ceiling_N); the default N > 1 mode of "
+                         "this bench is WEAK scaling (N x frames per batch), which keeps every GPU's launches as large as at N = 1")
 
     out = None
     if rank == 0:
@@ -354,6 +405,14 @@ def main():
         cf = os.path.join(ROOT, "profiles", "roofline_counters.json")
         if os.path.exists(cf):
             counters = json.load(open(cf)).get(args.workload, {})
+        # the counters describe the kernels they were collected from: a library built from other kernel sources makes them
+        # stale -- then no fraction is printed rather than a wrong one (profiles/make_counters.py records the hash)
+        src_now = kernel_source_hash()
+        stale = bool(counters) and counters.get("kernel_source_sha16") not in (None, src_now)
+        if stale:
+            print("bench.py: profiles/roofline_counters.json was collected from other kernel sources (%s, now %s): roofline.frac "
+                  "withheld -- re-run profiles/collect.sh + make_counters.py" % (counters.get("kernel_source_sha16"), src_now), file=sys.stderr)
+            counters = {"source": counters.get("source", "") + " (STALE: other kernel sources)", "frames_per_launch": counters.get("frames_per_launch")}
         kc = counters.get("kernels", {}).get(dominant, {})
         n_launch_frames = fpb // world                      # frames one launch of this rank covers
         # the counters were collected with `frames_per_launch` frames per launch (the default batch shape); another
@@ -384,6 +443,23 @@ def main():
                     "frac": round(tot / t_batch / VALU_PEAK_WAVE_INSTR_S, 4),
                     "what": "all kernels of a batch (SQ_INSTS_VALU per launch x launches per batch) / measured time per batch; "
                             "the dominant kernel's own `frac` is lower because %d batches share the chip" % args.slots}
+        # `frac` is an ISSUE rate, not an efficiency: a wave holds 16 rays and runs until its slowest ray is done, and an
+        # iteration issues the node path (46 instructions) and / or the leaf path (75) for all 16 quads whichever of them
+        # need it.  Useful = the steps live rays actually took, weighted the same way (statistics build, all k_trace
+        # launches of one batch)
+        useful = None
+        if shape["iterations"]:
+            C_NODE, C_LEAF = 46.0, 75.0
+            issued = 16.0 * (shape["node_path_issues"] * C_NODE + shape["leaf_path_issues"] * C_LEAF)
+            used = shape["node_steps"] * C_NODE + shape["leaf_steps"] * C_LEAF
+            w = float(max(shape["waves"], 1))
+            useful = {"value": round(used / issued, 4),
+                      "per_wave": {"iterations": round(shape["iterations"] / w, 2), "node_path_issues": round(shape["node_path_issues"] / w, 2),
+                                   "leaf_path_issues": round(shape["leaf_path_issues"] / w, 2),
+                                   "live_quad_steps": round(shape["live_quad_steps"] / w, 1), "issued_quad_slots": round(16.0 * shape["iterations"] / w, 1)},
+                      "what": "(node steps x 46 + leaf steps x 75 instructions of live rays) / (16 quads x (iterations issuing the node "
+                              "path x 46 + the leaf path x 75)): the share of k_trace's issued lane-work that advanced a ray; "
+                              "useful rate = frac x this"}
         roof = {"bound": "valu_issue", "kernel": KERNEL_LABEL[dominant],
                 "achieved": None if achieved is None else round(achieved / 1e9, 2),
                 "peak": round(VALU_PEAK_WAVE_INSTR_S / 1e9, 1), "unit": "G wave-instr/s",
@@ -411,7 +487,8 @@ def main():
                 "algorithmic_bytes_per_wave_pass": b_wp,
                 "measured_bytes_per_wave_pass": round(measured_b_wp, 1),
                 "algorithmic_GBps": (round(wp_launch * b_wp / live_s / 1e9, 2) if dominant in ("trace", "trace0") and live_s > 0 else None),
-                "frames_per_launch": n_launch_frames}
+                "frames_per_launch": n_launch_frames,
+                "useful_issue_frac": useful}
         out = {
             "metric": "polar images/sec (400 az x 3424 bins)",
             "value": round(img_per_s, 2),
@@ -440,6 +517,8 @@ def main():
             "prewarm_s": PREWARM_S,
             "host_resident": host_res,
             "single_pose": single,
+            "single_frame_sync": sync1,
+            "strong_scaling_proxy": proxy,
             "roofline": roof,
         }
 

@@ -232,6 +232,39 @@ int rr_simulate_material_sets_device(rr_ctx* ctx, const float pose[7], const rr_
 int rr_simulate_material_sets(rr_ctx* ctx, const float pose[7], const rr_material* sets, int n_sets,
                               size_t n_materials, uint8_t* out_imgs_u8);
 
+/* The whole parameter vector of the optimiser (scripts/radaray_opti.py:36-113: beam_width, n_reflections, 2 x 4 material
+ * values) batched the same way: set k = {material table, beam sample directions, number of ray-cast passes}, ONE pose,
+ * n_sets (1..RR_MAX_BATCH) images in one set of launches.
+ *   materials      [n_materials] (as many as rr_set_materials got), or NULL: the table of rr_set_materials
+ *   beam_dirs      [n_beam][3] with n_beam as given to rr_set_beam_samples (what sample_cone_local returns for this set's
+ *                  beam_width: rr_sample_cone_local), or NULL: the samples of rr_set_beam_samples.  Sets with the SAME
+ *                  directions (same pointer or same bytes) form a group: pass 0 does not depend on the materials and is
+ *                  traced once per group
+ *   n_reflections  0..16 passes for this set, negative: the config's.  A set with fewer passes than the others simply
+ *                  stops early (no live waves in the later launches); wave queues are sized for the largest
+ * Image k is bit-identical to rr_set_materials / rr_set_beam_samples / rr_set_config(n_reflections) of set k followed
+ * by rr_simulate_device(pose); every set sees the same noise realisation (row 0 of rr_set_noise_offsets). */
+typedef struct rr_param_set {
+    const rr_material* materials;
+    const float* beam_dirs;
+    int32_t n_reflections;
+    int32_t reserved_;
+} rr_param_set;
+int rr_simulate_param_sets_device(rr_ctx* ctx, const float pose[7], const rr_param_set* sets, int n_sets, size_t n_materials,
+                                  uint8_t* d_imgs_u8 /* [n_sets][n_cells][n_angles] in HBM */, void* stream);
+/* The objective of that optimiser is ONE float per evaluation -- minus the PSNR of the simulated image against one real
+ * radar image (radaray_opti.py:170-211, skimage.metrics.peak_signal_noise_ratio on mono8) -- so an evaluation need not
+ * ship 1.37 MB per set to the host: rr_score_images_device returns, for n images in HBM against one reference image in
+ * HBM, psnr[k] = 10 log10(255^2 / mean((img_k - ref)^2)) in f64 (+inf for identical images; the device part is the
+ * exact integer sum of squared differences, optionally returned in out_sse) to HOST arrays; synchronous on `stream`. */
+int rr_score_images_device(rr_ctx* ctx, const uint8_t* d_imgs_u8, int n_images, const uint8_t* d_ref_u8,
+                           double* out_psnr /* host [n_images], or NULL */, uint64_t* out_sse /* host [n_images], or NULL */, void* stream);
+/* Host-buffer form (synchronous) of the parameter batch: out_imgs_u8 [n_sets][n_cells][n_angles] or NULL; with
+ * ref_img_u8 (host, [n_cells][n_angles]) and out_psnr ([n_sets]) the scores come back as well -- with out_imgs_u8 NULL
+ * an evaluation of n_sets parameter vectors returns n_sets doubles and no image leaves the GPU. */
+int rr_simulate_param_sets(rr_ctx* ctx, const float pose[7], const rr_param_set* sets, int n_sets, size_t n_materials,
+                           uint8_t* out_imgs_u8, const uint8_t* ref_img_u8, double* out_psnr);
+
 /* All frames of a multi-frame step in ONE launch: frame j reads its columns frame_stride bytes after
  * frame j-1 (block addressing as above) and writes image j of d_imgs_u8 [n_frames][n_cells][n_angles]. */
 int rr_assemble_frames_device(rr_ctx* ctx, const uint8_t* d_cols_u8, int n_loc, size_t block_stride,
@@ -261,6 +294,14 @@ int rr_get_stats(rr_ctx* ctx, rr_stats* stats);
 /* stats mode: traversal counters (nodes_visited, tris_tested) on/off; off by
  * default because the counting kernel variant is slower. */
 int rr_set_stats_mode(rr_ctx* ctx, int enable);
+/* stats mode only: the wave-level shape of the traversal loop over the last frame (all k_trace launches), what
+ * separates the kernel's instruction ISSUE rate from useful work (bench.py: roofline.useful_issue_frac).  A wave holds
+ * 16 rays (one per quad of lanes) and iterates until its slowest ray is done; an iteration issues the node path if any
+ * quad holds a node and the leaf path if any holds a leaf.
+ *   out[0] waves   out[1] wave iterations   out[2] iterations that issued the node path   out[3] ... the leaf path
+ *   out[4] live quad-steps (ray steps that did work; 16 x out[1] were issued)   out[5] longest wave (iterations)
+ *   out[6] node steps of all rays (= nodes_visited)   out[7] leaf steps of all rays (= out[4] - out[6]) */
+int rr_get_traversal_shape(rr_ctx* ctx, uint64_t out[8]);
 
 /* ---- introspection used by tests / bench ---- */
 /* nearest-hit query for rays given in map coordinates (device traversal). */
@@ -330,6 +371,34 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
  * With ONE device a batch takes rr_simulate_batch_host_async's route (deferred, trickled host copy). */
 int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames, uint8_t* h_imgs_u8);
 int rr_multi_wait(rr_multi* m, const void* h_imgs_u8);
+
+/* ---- host side of the seam: what the reference does on the CPU around simulate() (no GPU involved) -----------------
+ * Beam samples = sample_cone_local (src/radarays_ros/radar_algorithms.cpp:248-294; erfinvf radar_math.h:13-44):
+ * RadarCPU::simulate re-draws m_waves_start whenever a dynamic reconfigure changed beam_width / n_samples /
+ * beam_sample_dist / p_in_cone (RadarCPU.cpp:136-145).  rr_cone_dirs is the geometry on caller-supplied variates
+ * (u_angle in [0, 1) -> angle, r_variate: U(0,1) for sample_dist 0 / 1, N(0,1) for 2 / 3), bit-equal to the oracle's
+ * restatement; rr_sample_cone_local draws the variates itself from a SEEDED MT19937 (the reference seeds from
+ * std::random_device: unreproducible) in numpy.random.RandomState's streams, so that it returns the directions
+ * radarays_ros_amd/beams.py: sample_cone_local(seed) returns.  width_rad = RadarModel.beam_width (radians);
+ * out_dirs [n][3], local azimuth frame, ready for rr_set_beam_samples. */
+int rr_cone_dirs(float width_rad, int sample_dist, float p_in_cone, const float* u_angle, const float* r_variate, size_t n,
+                 float* out_dirs);
+int rr_sample_cone_local(uint32_t seed, float width_rad, size_t n, int sample_dist, float p_in_cone, float* out_dirs);
+
+/* The map file, as rm::import_embree_map(map_file) reads it for the node (src/radar_simulator.cpp:149): PLY (ascii,
+ * binary little / big endian; MulRan maps, launch/mulran_sim.launch:7) and Wavefront OBJ (objects `o` / `g` become
+ * object ids, the index into object_materials) into the flat arrays rr_set_mesh takes; polygons are fan-triangulated.
+ * The arrays are malloc'ed: give them back with rr_free_mesh.  <0 + text in err on failure.  (COLLADA: meshio.py.) */
+typedef struct rr_mesh {
+    float* verts;               /* [n_verts][3] */
+    size_t n_verts;
+    uint32_t* faces;            /* [n_faces][3] */
+    size_t n_faces;
+    uint32_t* face_object_id;   /* [n_faces] */
+    size_t n_objects;           /* OBJ: number of o / g groups (>= 1) */
+} rr_mesh;
+int rr_load_mesh_file(const char* path, rr_mesh* out, char* err, size_t err_len);
+void rr_free_mesh(rr_mesh* m);
 
 /* ---- environment switches (read at rr_create / at a build; none is needed in normal use) --------------------------
  * RR_LANES (4)            frame buffer sets = batches that can be in flight (1..8)

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <iostream>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -122,9 +123,13 @@ public:
     RadarHIP(const RadarHIP&) = delete;
     RadarHIP& operator=(const RadarHIP&) = delete;
 
-    // m_waves_start: the reference draws them with sample_cone_local from std::random_device
-    // (RadarCPU.cpp:136-145); here they are supplied (any generator) -- [n][3], local frame
+    // m_waves_start: RadarCPU::simulate draws them with sample_cone_local whenever m_resample is set (RadarCPU.cpp:136-145),
+    // seeding from std::random_device.  push() does the same (rr_sample_cone_local); setBeamSeed() makes the draw
+    // reproducible, setBeamSamples() injects directions from any other generator -- [n][3], local frame -- until the next
+    // dynamic reconfigure of the beam asks for a re-draw again
+    void setBeamSeed(uint32_t seed) { m_beam_seed = seed; m_have_seed = true; }
     void setBeamSamples(const std::vector<float>& dirs) { m_waves_start = dirs; m_resample = false; m_push_beams = true; }
+    const std::vector<float>& beamSamples() const { return m_waves_start; }
     void setNoiseOffsets(const std::vector<float>& rnd) { rr_multi_set_noise_offsets(m_multi, rnd.data(), rnd.size()); }
     // include_motion (cfg/RadarModel.cfg:85, RadarCPU.cpp:190-196): the reference looks Tsm up once PER AZIMUTH while
     // the antenna turns; the TF lookups of one sweep arrive here as [n_angles][7] and are used while
@@ -176,6 +181,52 @@ public:
         }
         return out;
     }
+    // The same action with the optimiser's WHOLE parameter vector (scripts/radaray_opti.py:36-113: model.beam_width,
+    // model.n_reflections, the material values): one RadarParams per evaluation, one call for all of them
+    // (rr_simulate_param_sets: sets with the same beam_width share pass 0, sets with fewer passes stop early).  The beam of
+    // a set is drawn like push() draws it -- same seed for every set, so equal widths give equal directions;
+    // model.n_samples must be the current one.  `real` given: the objective values of radaray_opti.py:196 come back
+    // (PSNR against the real image, skimage's formula; the optimiser minimises its negative) and, with want_images false,
+    // no image leaves the GPU.
+    bool simulateParamSets(const std::vector<RadarParams>& sets, double stamp, std::vector<ImagePtr>* images,
+                           const Image* real = nullptr, std::vector<double>* psnr = nullptr)
+    {
+        if (!updateTsm()) { std::cout << "Couldn't get Transform between sensor and map. Skipping..." << std::endl; return false; }
+        if (!push()) return false;
+        const size_t n_mat = m_params.materials.size(), nb = m_params.model.n_samples;
+        const size_t npx = (size_t)m_cfg.n_cells * m_n_angles;
+        if (real && (real->data.size() != npx || !psnr)) { m_err = "the real image must be n_cells x n_angles mono8 (and psnr given)"; return false; }
+        std::vector<rr_material> flat; flat.reserve(sets.size() * n_mat);
+        std::vector<std::vector<float>> dirs(sets.size());
+        std::vector<rr_param_set> ps(sets.size());
+        const uint32_t seed = m_have_seed ? m_beam_seed : (uint32_t)std::random_device{}();
+        for (size_t k = 0; k < sets.size(); k++) {
+            const RadarParams& p = sets[k];
+            if (p.materials.size() != n_mat || p.model.n_samples != nb) { m_err = "every parameter set needs the loaded number of materials and the current n_samples"; return false; }
+            for (const RadarMaterial& m : p.materials) flat.push_back({ m.velocity, m.ambient, m.diffuse, m.specular });
+            if (std::abs(p.model.beam_width - m_params.model.beam_width) > 1e-7f) {
+                dirs[k].assign(3 * nb, 0.0f);
+                if (rr_sample_cone_local(seed, p.model.beam_width, nb, m_cfg.beam_sample_dist, (float)m_cfg.beam_sample_dist_normal_p_in_cone, dirs[k].data())) { m_err = "sample_cone_local failed"; return false; }
+            }
+            ps[k].n_reflections = (int32_t)p.model.n_reflections; ps[k].reserved_ = 0;
+        }
+        for (size_t k = 0; k < sets.size(); k++) { ps[k].materials = flat.data() + k * n_mat; ps[k].beam_dirs = dirs[k].empty() ? nullptr : dirs[k].data(); }
+        std::vector<uint8_t> px(images ? sets.size() * npx : 0);
+        if (psnr) psnr->assign(sets.size(), 0.0);
+        if (rr_simulate_param_sets(m_ctx, Tsm_last, ps.data(), (int)sets.size(), n_mat, images ? px.data() : nullptr,
+                                   real ? real->data.data() : nullptr, real ? psnr->data() : nullptr)) { fail(); return false; }
+        if (images) {
+            images->clear();
+            for (size_t k = 0; k < sets.size(); k++) {
+                ImagePtr msg = std::make_shared<Image>();
+                msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;
+                msg->data.assign(px.begin() + k * npx, px.begin() + (k + 1) * npx);
+                msg->stamp = stamp; msg->frame_id = m_sensor_frame;
+                images->push_back(msg);
+            }
+        }
+        return true;
+    }
     const std::string& lastError() const { return m_err; }
     const rr_stats& lastStats() const { return m_stats; }
 
@@ -183,7 +234,16 @@ private:
     // marshal the protected state of Radar into the context (what simulate() reads, Radar.hpp:66-105)
     bool push()
     {
-        if (m_resample || m_waves_start.empty()) { m_err = "beam samples not set (setBeamSamples)"; return false; }
+        if (m_resample || m_waves_start.empty()) {    // RadarCPU.cpp:136-145
+            const size_t n = m_params.model.n_samples;
+            m_waves_start.assign(3 * n, 0.0f);
+            const uint32_t seed = m_have_seed ? m_beam_seed : (uint32_t)std::random_device{}();
+            if (rr_sample_cone_local(seed, m_params.model.beam_width, n, m_cfg.beam_sample_dist,
+                                     (float)m_cfg.beam_sample_dist_normal_p_in_cone, m_waves_start.data())) {
+                m_err = "sample_cone_local: beam_sample_dist must be 0..3"; std::cout << "[RadarHIP] " << m_err << std::endl; return false;
+            }
+            m_resample = false; m_push_beams = true;
+        }
         if (m_dirty_cfg) {
             rr_config c; rr_default_config(&c);
             c.n_cells = m_cfg.n_cells; c.n_reflections = (int)m_params.model.n_reflections;
@@ -236,6 +296,7 @@ private:
     std::vector<float> m_motion; bool m_push_motion = false;
     int m_n_angles = 400;
     bool m_push_beams = false;
+    uint32_t m_beam_seed = 0; bool m_have_seed = false;
     rr_stats m_stats{};
     std::string m_err;
 };

@@ -332,24 +332,31 @@ void orc_make_denoiser(int kind, int width, int mode, int rescale, float* out)
     }
 }
 
+/* radar_algorithms.cpp:263-280: the radius law of one sample (D1..D4 of scripts/radaray_beams.py:23-25,78-92) */
+float orc_cone_radius(float width, int sample_dist, float p_in_cone, float variate)
+{
+    float z = (float)(M_SQRT2 * (double)orc_erfinvf(p_in_cone));   /* :263 */
+    float radius = (float)((double)width / 2.0);                    /* :265 */
+    float random_radius = 0.0f;
+    if (sample_dist == 0) {
+        random_radius = variate * radius;
+    } else if (sample_dist == 1) {
+        random_radius = sqrtf(variate) * radius;
+    } else if (sample_dist == 2) {
+        random_radius = (variate / z) * radius;
+    } else if (sample_dist == 3) {
+        random_radius = sqrtf(fabsf(variate) / z) * radius;
+    }
+    return random_radius;
+}
+
 /* radar_algorithms.cpp:248-294 with externally supplied variates */
 void orc_sample_cone_local(float width, int n_samples, int sample_dist, float p_in_cone,
                            const float* u_angle, const float* r_variate, float* out_dirs)
 {
-    float z = (float)(M_SQRT2 * (double)orc_erfinvf(p_in_cone));   /* :263 */
-    float radius = (float)((double)width / 2.0);                    /* :265 */
     for (int i = 0; i < n_samples; i++) {
         float random_angle = (float)((double)(u_angle[i] * 2.0f) * M_PI - M_PI);   /* :269 */
-        float random_radius = 0.0f;
-        if (sample_dist == 0) {
-            random_radius = r_variate[i] * radius;
-        } else if (sample_dist == 1) {
-            random_radius = sqrtf(r_variate[i]) * radius;
-        } else if (sample_dist == 2) {
-            random_radius = (r_variate[i] / z) * radius;
-        } else if (sample_dist == 3) {
-            random_radius = sqrtf(fabsf(r_variate[i]) / z) * radius;
-        }
+        float random_radius = orc_cone_radius(width, sample_dist, p_in_cone, r_variate[i]);
         float alpha = random_radius * cosf(random_angle);   /* :282 */
         float beta = random_radius * sinf(random_angle);
         quat q = q_from_euler(0.0f, alpha, beta);           /* :285 */

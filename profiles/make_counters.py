@@ -18,6 +18,11 @@ out["_how"] = ("rocprofv3 --pmc <counters> --kernel-trace (separate passes: FETC
                "coalesced streams, not for 16-B gathers, and WRITE_SIZE counts 4-B scattered stores as partial lines: hbm_bytes is an estimate.")
 
 
+sys.path.insert(0, os.path.dirname(here))
+from bench import kernel_source_hash        # the sources the counters were collected from (run this right after collect.sh)
+src_hash = kernel_source_hash()
+
+
 def classify(name):
     n = name.replace("void ", "").replace("rr::", "")
     if n.startswith("k_trace"):
@@ -64,6 +69,7 @@ for wl, suffix in pairs:
             b = json.load(open(bf)); fpl = int(b["config"]["frames_per_batch"]) // max(int(b["n_gpus"]), 1)
         except Exception:
             pass
-    out[wl] = {"source": "profiles/%s%s_pmc_summary.json" % (tag, suffix), "frames_per_launch": fpl, "kernels": kernels}
+    out[wl] = {"source": "profiles/%s%s_pmc_summary.json" % (tag, suffix), "frames_per_launch": fpl, "kernels": kernels,
+               "kernel_source_sha16": src_hash}
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {kk: vv.get("SQ_INSTS_VALU") for kk, vv in v["kernels"].items()} for k, v in out.items() if k != "_how"}, indent=1))

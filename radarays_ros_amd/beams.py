@@ -58,14 +58,13 @@ def variates(n_samples, sample_dist, seed):
     return u_angle, r
 
 
-def cone_dirs(width_rad, sample_dist, p_in_cone, u_angle, r_variate):
-    """radar_algorithms.cpp:263-289 on given variates -> [n][3] float32."""
+def cone_radius(width, sample_dist, p_in_cone, r_variate):
+    """radar_algorithms.cpp:263-280: the radius law D1..D4 (scripts/radaray_beams.py:23-25,78-92) in float32;
+    `width` in any angular unit, the radius comes back in the same."""
     f = np.float32
-    u_angle = np.asarray(u_angle, f)
     r_variate = np.asarray(r_variate, f)
     z = f(np.float64(np.sqrt(2.0)) * np.float64(erfinvf(p_in_cone)))
-    radius = f(np.float64(f(width_rad)) / 2.0)
-    ang = (np.float64(u_angle * f(2.0)) * np.pi - np.pi).astype(f)
+    radius = f(np.float64(f(width)) / 2.0)
     if sample_dist == 0:
         rr = r_variate * radius
     elif sample_dist == 1:
@@ -76,7 +75,15 @@ def cone_dirs(width_rad, sample_dist, p_in_cone, u_angle, r_variate):
         rr = np.sqrt(np.abs(r_variate) / z) * radius
     else:
         raise ValueError("beam_sample_dist must be 0..3")
-    rr = rr.astype(f)
+    return rr.astype(f)
+
+
+def cone_dirs(width_rad, sample_dist, p_in_cone, u_angle, r_variate):
+    """radar_algorithms.cpp:263-289 on given variates -> [n][3] float32."""
+    f = np.float32
+    u_angle = np.asarray(u_angle, f)
+    ang = (np.float64(u_angle * f(2.0)) * np.pi - np.pi).astype(f)
+    rr = cone_radius(width_rad, sample_dist, p_in_cone, r_variate)
     alpha = (rr * np.cos(ang)).astype(f)
     beta = (rr * np.sin(ang)).astype(f)
     q = _quat_from_euler(np.zeros_like(alpha), alpha, beta)

@@ -31,6 +31,7 @@ void launch_debug_trace(const Params& P, const float* origs, const float* dirs, 
                         float* out_t, uint32_t* out_face, hipStream_t s);
 void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s);
 void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s);
+void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
 }  // namespace rr
 
 using namespace rr;
@@ -79,6 +80,10 @@ struct Lane {
     DevBuf<SegStats> d_seg_stats;
     DevBuf<float4> d_matsets;     // material sets of a parameter batch [n_sets][n_materials]
     DevBuf<double> d_matset_limits;   // ... and their angles of total reflection (k_mat_limits)
+    // ... and its beam tables [n_groups][n_beam] with their two trace orders; the host arrays they are copied from stay
+    // alive with the lane (a copy from pageable memory may still be staged when the call returns)
+    DevBuf<float4> d_set_beams; DevBuf<uint32_t> d_set_order, d_set_order2;
+    std::vector<float4> h_set_beams, h_matsets; std::vector<uint32_t> h_set_order, h_set_order2;
     int last_n_seg = 0, last_n_passes = 0;
     int spill_stride = 0, stack_lds = 1;
 
@@ -157,6 +162,8 @@ struct rr_ctx {
         hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
     }
 
+    int passes_override = -1;    // a parameter batch in the making: the largest n_reflections of its sets sizes queues and launch loops
+    DevBuf<unsigned long long> d_sse; DevBuf<uint8_t> d_ref_img;     // rr_score_images / rr_simulate_param_sets
     void* h_frame = nullptr; size_t h_frame_bytes = 0;   // page-locked: error bits + per-pass counters of rr_simulate's frame
 
     bool roctx = false;
@@ -238,6 +245,11 @@ void make_smear(const rr_config& cfg, std::vector<float>& w, int& mode)
     for (int i = 0; i < width; i++) w[i] = (float)((double)w[i] / mode_val);
 }
 
+// number of ray-cast passes the frame buffers and the launch loop are sized for: the config's, or the largest of a
+// parameter batch while rr_simulate_param_sets_device assembles it
+inline int eff_passes(const rr_ctx* c) { return c->passes_override >= 0 ? c->passes_override : c->cfg.n_reflections; }
+inline rr_config eff_config(const rr_ctx* c) { rr_config g = c->cfg; g.n_reflections = eff_passes(c); return g; }
+
 int wave_capacity(const rr_config& cfg, int n_beam)
 {
     long cap = cfg.max_waves_per_azimuth;
@@ -256,6 +268,27 @@ int signal_capacity(const rr_config& cfg, int n_beam, int cap)
     for (int p = 0; p < cfg.n_reflections; p++) { tot += std::min<long>(w, cap); w = std::min<long>(2 * w, cap); }
     if (cfg.record_multi_path) tot *= 2;
     return (int)std::max<long>(tot, 1);
+}
+
+// trace orders of a beam table (results are always stored under the reference index, so they only change speed):
+//   pass 0     : k_trace tiles (beam sample, azimuth) into waves itself (see there); this order
+//                decides which samples share a tile / are neighbours in the launch: rows of nearly
+//                equal elevation, sorted by yaw inside a row
+//   pass 1 ... : inherited through torder from a second order of the beam samples, yaw-major rows
+//                (the reflected fan of a yaw slice stays together; measured against elevation-major
+//                and Morton orders)
+void beam_trace_orders(const float* beams, size_t nb, std::vector<uint32_t>& order, std::vector<uint32_t>& order2)
+{
+    auto make_order = [&](int major, std::vector<uint32_t>& o) {   // major: 2 = elevation (z), 1 = yaw (y)
+        o.resize(nb);
+        for (size_t i = 0; i < nb; i++) o[i] = (uint32_t)i;
+        const int minor = 3 - major;
+        std::stable_sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) { return beams[3 * a + major] < beams[3 * b + major]; });
+        for (size_t i = 0; i < nb; i += 16)
+            std::stable_sort(o.begin() + i, o.begin() + std::min(nb, i + 16), [&](uint32_t a, uint32_t b) { return beams[3 * a + minor] < beams[3 * b + minor]; });
+    };
+    make_order(2, order);
+    make_order(1, order2);
 }
 
 int upload_tables(rr_ctx* c)
@@ -291,24 +324,8 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, c->d_beams.ensure(nb));
     if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
     {
-        // trace orders (results are always stored under the reference index, so they only change speed):
-        //   pass 0     : k_trace tiles (beam sample, azimuth) into waves itself (see there); this order
-        //                decides which samples share a tile / are neighbours in the launch: rows of nearly
-        //                equal elevation, sorted by yaw inside a row
-        //   pass 1 ... : inherited through torder from a second order of the beam samples, yaw-major rows
-        //                (the reflected fan of a yaw slice stays together; measured against elevation-major
-        //                and Morton orders)
-        auto make_order = [&](int major, std::vector<uint32_t>& order) {   // major: 2 = elevation (z), 1 = yaw (y)
-            order.resize(nb);
-            for (size_t i = 0; i < nb; i++) order[i] = (uint32_t)i;
-            const int minor = 3 - major;
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + major] < c->beams[3 * b + major]; });
-            for (size_t i = 0; i < nb; i += 16)
-                std::stable_sort(order.begin() + i, order.begin() + std::min(nb, i + 16), [&](uint32_t a, uint32_t b) { return c->beams[3 * a + minor] < c->beams[3 * b + minor]; });
-        };
         std::vector<uint32_t> order, order2;
-        make_order(2, order);
-        make_order(1, order2);
+        beam_trace_orders(c->beams.data(), nb, order, order2);
         RR_HIP(c, c->d_beam_order2.ensure(nb));
         if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order2.p, order2.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
         RR_HIP(c, c->d_beam_order.ensure(nb));
@@ -367,7 +384,7 @@ int upload_tables(rr_ctx* c)
 
 int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
 {
-    const rr_config& g = c->cfg;
+    const rr_config g = eff_config(c);      // (a parameter batch may ask for more passes than the config)
     const int n_beam = (int)(c->beams.size() / 3);
     const int cap = wave_capacity(g, n_beam);
     const int sigcap = signal_capacity(g, n_beam, cap);
@@ -418,7 +435,7 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
 // with a stale pointer.  Frames still in flight may use the old buffers: drain the device first.
 int prepare_lane(rr_ctx* c, Lane& L, int n_seg, bool want_f32 = false)
 {
-    const rr_config& g = c->cfg;
+    const rr_config g = eff_config(c);      // (a parameter batch may ask for more passes than the config)
     const int n_beam = (int)(c->beams.size() / 3);
     const int cap = wave_capacity(g, n_beam);
     const bool fits = L.buf_seg >= n_seg && cap == L.buf_cap && g.n_cells == L.buf_cells &&
@@ -432,7 +449,7 @@ int prepare_lane(rr_ctx* c, Lane& L, int n_seg, bool want_f32 = false)
 void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begin, int n_seg,
                  uint8_t* d_cols_u8, float* d_cols_f32)
 {
-    const rr_config& g = c->cfg;
+    const rr_config g = eff_config(c);      // (a parameter batch may ask for more passes than the config)
     std::memset(&P, 0, sizeof(P));
     P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
     P.tri_base4 = c->tri_base4;
@@ -532,12 +549,20 @@ int check_ready(rr_ctx* c)
     return 0;
 }
 
+// a parameter batch as run_frame sees it: per frame its passes and beam group, per group the frame pass 0 is traced for
+struct SetPlan {
+    int n_groups = 1;
+    unsigned char frame_passes[64], frame_beam[64], group_frame[64];
+    const float4* d_beams = nullptr; const uint32_t* d_order = nullptr; const uint32_t* d_order2 = nullptr;   // [n_groups][n_beam]; null: the ctx's tables
+};
+
 int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
               uint8_t* d_cols_u8 /* null: the lane's own buffer */, float* d_cols_f32, hipStream_t s, int n_frames = 1,
               const float4* d_matsets = nullptr, int mat_stride = 0, bool lane_f32 = false,
-              const uint8_t* copy_src = nullptr, uint8_t* copy_dst = nullptr, size_t copy_bytes = 0)
+              const uint8_t* copy_src = nullptr, uint8_t* copy_dst = nullptr, size_t copy_bytes = 0,
+              const SetPlan* plan = nullptr)
 {
-    const rr_config& g = c->cfg;
+    const rr_config g = eff_config(c);      // (a parameter batch may ask for more passes than the config)
     if (az_begin < 0 || az_end > g.n_angles || az_begin > az_end) return fail(c, -3, "azimuth range out of bounds");
     const int n_loc = az_end - az_begin;
     const int n_seg = n_loc * n_frames;
@@ -554,9 +579,20 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     fill_params(c, L, P, pose, az_begin, n_seg, d_cols_u8, d_cols_f32);
     P.n_loc = n_loc; P.n_frames = n_frames;
     if (d_matsets) {   // parameter batch: one pose, one material table per frame
-        P.materials = d_matsets; P.mat_limits = L.d_matset_limits.p; P.mat_stride = mat_stride; P.share_first = 1;
-        P.noise_rows = 1;     // every set is the SAME frame under another material table: one noise realisation (row 0)
+        P.materials = d_matsets; P.mat_limits = L.d_matset_limits.p; P.mat_stride = mat_stride;
+        P.set_mode = 1;
+        P.noise_rows = 1;     // every set is the SAME frame under another parameter set: one noise realisation (row 0)
         for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[k];
+        SetPlan dflt;
+        if (!plan) {          // material sets only: one beam, every frame the config's passes
+            for (int f = 0; f < n_frames; f++) { dflt.frame_passes[f] = (unsigned char)g.n_reflections; dflt.frame_beam[f] = 0; }
+            dflt.group_frame[0] = 0; plan = &dflt;
+        }
+        P.n_groups = plan->n_groups;
+        std::memcpy(P.frame_passes, plan->frame_passes, (size_t)n_frames);
+        std::memcpy(P.frame_beam, plan->frame_beam, (size_t)n_frames);
+        std::memcpy(P.group_frame, plan->group_frame, (size_t)plan->n_groups);
+        if (plan->d_beams) { P.beams = plan->d_beams; P.beam_order = plan->d_order; P.beam_order2 = plan->d_order2; }
     } else
     for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[7 * f + k];
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
@@ -686,13 +722,13 @@ void rr_destroy(rr_ctx* c)
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release(); c->d_mat_limits.release();
-    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_beam_order.release(); c->d_beam_order2.release(); c->d_motion.release();
+    c->d_objmat.release(); c->d_smear.release(); c->d_noise.release(); c->d_decay.release(); c->d_param_imgs.release(); c->d_sse.release(); c->d_ref_img.release(); c->d_beam_order.release(); c->d_beam_order2.release(); c->d_motion.release();
     for (Lane& L : c->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (int k = 0; k < 2; k++) { L.d_wA[k].release(); L.d_wB[k].release(); L.d_wC[k].release(); L.d_idx[k].release(); L.d_count[k].release(); L.d_torder[k].release(); }
         L.d_refpos.release();
         L.d_hit.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
-        L.d_sigtmp.release(); L.d_sig.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_matset_limits.release(); L.d_img_u8.release(); L.d_img_f32.release();
+        L.d_sigtmp.release(); L.d_sig.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_matset_limits.release(); L.d_set_beams.release(); L.d_set_order.release(); L.d_set_order2.release(); L.d_img_u8.release(); L.d_img_f32.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         for (Lane::CopyRec& r : L.rec) if (r.ev) (void)hipEventDestroy(r.ev);
@@ -1045,21 +1081,45 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
     return 0;
 }
 
-int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets,
-                                     size_t n_materials, uint8_t* d_imgs_u8, void* stream)
+int rr_simulate_param_sets_device(rr_ctx* c, const float pose[7], const rr_param_set* sets, int n_sets, size_t n_materials,
+                                  uint8_t* d_imgs_u8, void* stream)
 {
     int rc = check_ready(c); if (rc) return rc;
-    if (!pose || !sets || !d_imgs_u8) return fail(c, -3, "rr_simulate_material_sets_device: null pose/sets/output");
-    if (n_sets < 1 || n_sets > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_material_sets_device: n_sets must be 1..64");
+    if (!pose || !sets || !d_imgs_u8) return fail(c, -3, "rr_simulate_param_sets_device: null pose/sets/output");
+    if (n_sets < 1 || n_sets > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_param_sets_device: n_sets must be 1..64");
     const size_t n_mat = c->materials.size();
     if (n_materials != n_mat)
-        return fail(c, -3, "rr_simulate_material_sets_device: every set must hold as many materials as the table given to rr_set_materials");
-    for (size_t i = 0; i < (size_t)n_sets * n_mat; i++)
-        if (!std::isfinite(sets[i].velocity) || !std::isfinite(sets[i].ambient) || !std::isfinite(sets[i].diffuse) ||
-            !std::isfinite(sets[i].specular))
-            return fail(c, -3, "rr_simulate_material_sets_device: non-finite material parameter");
+        return fail(c, -3, "rr_simulate_param_sets_device: every set must hold as many materials as the table given to rr_set_materials");
+    const size_t nb = c->beams.size() / 3;
+    if (nb == 0) return fail(c, -2, "rr_set_beam_samples has not been called");
+    int p_max = 0;
+    SetPlan plan; plan.n_groups = 0;
+    std::vector<const float*> group_dirs;         // beam table of each group (null: the ctx's own samples)
+    for (int k = 0; k < n_sets; k++) {
+        const rr_param_set& S = sets[k];
+        const int np = S.n_reflections < 0 ? c->cfg.n_reflections : S.n_reflections;
+        if (np > 16) return fail(c, -3, "rr_simulate_param_sets_device: n_reflections must be <= 16 (negative: the config's)");
+        p_max = std::max(p_max, np);
+        plan.frame_passes[k] = (unsigned char)np;
+        if (S.materials)
+            for (size_t i = 0; i < n_mat; i++)
+                if (!std::isfinite(S.materials[i].velocity) || !std::isfinite(S.materials[i].ambient) || !std::isfinite(S.materials[i].diffuse) ||
+                    !std::isfinite(S.materials[i].specular))
+                    return fail(c, -3, "rr_simulate_param_sets_device: non-finite material parameter");
+        if (S.beam_dirs) for (size_t i = 0; i < 3 * nb; i++) if (!std::isfinite(S.beam_dirs[i])) return fail(c, -3, "rr_simulate_param_sets_device: non-finite beam direction");
+        // sets with the same directions (the same pointer, or the same bytes) form a group and share pass 0
+        const float* dirs = S.beam_dirs;
+        if (dirs && std::memcmp(dirs, c->beams.data(), 3 * nb * sizeof(float)) == 0) dirs = nullptr;
+        int g = -1;
+        for (int j = 0; j < plan.n_groups && g < 0; j++) {
+            const float* o = group_dirs[(size_t)j];
+            if (o == dirs || (o && dirs && std::memcmp(o, dirs, 3 * nb * sizeof(float)) == 0)) g = j;
+        }
+        if (g < 0) { g = plan.n_groups++; group_dirs.push_back(dirs); plan.group_frame[g] = (unsigned char)k; }
+        plan.frame_beam[k] = (unsigned char)g;
+    }
     RR_HIP(c, hipSetDevice(c->device));
-    const rr_config& g = c->cfg;
+    const rr_config& g0 = c->cfg;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     rc = upload_tables(c); if (rc) return rc;
     const size_t li = c->next_lane++ % c->lanes.size();
@@ -1068,24 +1128,94 @@ int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_ma
     c->last_lane = li;
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     static_assert(sizeof(rr_material) == sizeof(float4), "rr_material is {velocity, ambient, diffuse, specular}");
-    if (L.d_matsets.n < (size_t)n_sets * n_mat) {
-        RR_HIP(c, hipDeviceSynchronize());      // the table of this lane may still be read by an earlier step
+    const size_t G = (size_t)plan.n_groups;
+    const bool own_beams = !(G == 1 && group_dirs[0] == nullptr);
+    if (L.d_matsets.n < (size_t)n_sets * n_mat || (own_beams && L.d_set_beams.n < G * nb)) {
+        RR_HIP(c, hipDeviceSynchronize());      // the tables of this lane may still be read by an earlier step
         RR_HIP(c, L.d_matsets.ensure((size_t)n_sets * n_mat));
         RR_HIP(c, L.d_matset_limits.ensure((size_t)n_sets * n_mat));
+        if (own_beams) { RR_HIP(c, L.d_set_beams.ensure(G * nb)); RR_HIP(c, L.d_set_order.ensure(G * nb)); RR_HIP(c, L.d_set_order2.ensure(G * nb)); }
     }
-    rc = prepare_lane(c, L, n_sets * g.n_angles); if (rc) return rc;
-    // pageable source: the copy is staged before the call returns, the caller's array is free again
-    RR_HIP(c, hipMemcpyAsync(L.d_matsets.p, sets, (size_t)n_sets * n_mat * sizeof(float4), hipMemcpyHostToDevice, s));
-    launch_mat_limits(L.d_matsets.p, (size_t)n_sets * n_mat, L.d_matset_limits.p, s);
-    rc = run_frame(c, L, pose, 0, g.n_angles, nullptr, nullptr, s, n_sets, L.d_matsets.p, (int)n_mat); if (rc) return rc;
+    // the lane's previous use of these host arrays: its copies were enqueued on a stream this stream now waits for
+    // (ev_consumed), but a staged copy reads the host side at an unknown time: wait for the lane's last batch before reuse
+    if (L.pending_consume) RR_HIP(c, hipEventSynchronize(L.ev_consumed));
+    L.h_matsets.resize((size_t)n_sets * n_mat);
+    for (int k = 0; k < n_sets; k++) {
+        const rr_material* m = sets[k].materials ? sets[k].materials : c->materials.data();
+        for (size_t i = 0; i < n_mat; i++) L.h_matsets[(size_t)k * n_mat + i] = make_float4(m[i].velocity, m[i].ambient, m[i].diffuse, m[i].specular);
+    }
+    if (own_beams) {
+        L.h_set_beams.resize(G * nb); L.h_set_order.resize(G * nb); L.h_set_order2.resize(G * nb);
+        std::vector<uint32_t> o1, o2;
+        for (size_t gi = 0; gi < G; gi++) {
+            const float* d = group_dirs[gi] ? group_dirs[gi] : c->beams.data();
+            for (size_t i = 0; i < nb; i++) L.h_set_beams[gi * nb + i] = make_float4(d[3 * i], d[3 * i + 1], d[3 * i + 2], 0.0f);
+            beam_trace_orders(d, nb, o1, o2);
+            std::copy(o1.begin(), o1.end(), L.h_set_order.begin() + (std::ptrdiff_t)(gi * nb));
+            std::copy(o2.begin(), o2.end(), L.h_set_order2.begin() + (std::ptrdiff_t)(gi * nb));
+        }
+        plan.d_beams = L.d_set_beams.p; plan.d_order = L.d_set_order.p; plan.d_order2 = L.d_set_order2.p;
+    }
+    // sizes follow the largest number of passes of the batch
+    c->passes_override = p_max;
+    rc = prepare_lane(c, L, n_sets * g0.n_angles);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(L.d_matsets.p, L.h_matsets.data(), L.h_matsets.size() * sizeof(float4), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && own_beams) e = hipMemcpyAsync(L.d_set_beams.p, L.h_set_beams.data(), G * nb * sizeof(float4), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && own_beams) e = hipMemcpyAsync(L.d_set_order.p, L.h_set_order.data(), G * nb * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && own_beams) e = hipMemcpyAsync(L.d_set_order2.p, L.h_set_order2.data(), G * nb * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) rc = fail(c, -100, std::string("rr_simulate_param_sets_device: ") + hipGetErrorString(e));
+    }
+    if (!rc) {
+        launch_mat_limits(L.d_matsets.p, (size_t)n_sets * n_mat, L.d_matset_limits.p, s);
+        rc = run_frame(c, L, pose, 0, g0.n_angles, nullptr, nullptr, s, n_sets, L.d_matsets.p, (int)n_mat, false, nullptr, nullptr, 0, &plan);
+    }
+    c->passes_override = -1;
+    if (rc) return rc;
     { TimedScope t(c, s, "assemble");
-      launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
-                         (size_t)g.n_angles * g.n_cells, n_sets, (size_t)g.n_angles * g.n_cells); }
+      launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g0.n_angles, g0.n_cells, g0.scroll_image, s, g0.n_angles,
+                         (size_t)g0.n_angles * g0.n_cells, n_sets, (size_t)g0.n_angles * g0.n_cells); }
     RR_HIP(c, hipGetLastError());
     RR_HIP(c, hipEventRecord(L.ev_consumed, s));
     L.pending_consume = true;
     return 0;
 }
+
+int rr_simulate_material_sets_device(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets,
+                                     size_t n_materials, uint8_t* d_imgs_u8, void* stream)
+{
+    if (!c) return -1;
+    if (!pose || !sets || !d_imgs_u8) return fail(c, -3, "rr_simulate_material_sets_device: null pose/sets/output");
+    if (n_sets < 1 || n_sets > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_material_sets_device: n_sets must be 1..64");
+    if (n_materials != c->materials.size())
+        return fail(c, -3, "rr_simulate_material_sets_device: every set must hold as many materials as the table given to rr_set_materials");
+    // the parameter batch with only the material tables varying: one beam group, the config's passes
+    rr_param_set ps[RR_MAX_BATCH];
+    for (int k = 0; k < n_sets; k++) { ps[k].materials = sets + (size_t)k * n_materials; ps[k].beam_dirs = nullptr; ps[k].n_reflections = -1; ps[k].reserved_ = 0; }
+    return rr_simulate_param_sets_device(c, pose, ps, n_sets, n_materials, d_imgs_u8, stream);
+}
+
+namespace {
+// the images of a parameter batch in c->d_param_imgs: copy out and / or score, report the frame's error bits
+int finish_param_batch(rr_ctx* c, int n_sets, uint8_t* out_imgs_u8, const uint8_t* ref_img_u8, double* out_psnr)
+{
+    const size_t npx = (size_t)c->cfg.n_cells * c->cfg.n_angles;
+    if (out_imgs_u8) RR_HIP(c, hipMemcpyAsync(out_imgs_u8, c->d_param_imgs.p, (size_t)n_sets * npx, hipMemcpyDeviceToHost, c->stream));
+    if (ref_img_u8 && out_psnr) {
+        RR_HIP(c, c->d_ref_img.ensure(npx));
+        RR_HIP(c, hipMemcpyAsync(c->d_ref_img.p, ref_img_u8, npx, hipMemcpyHostToDevice, c->stream));
+        const int rc = rr_score_images_device(c, c->d_param_imgs.p, n_sets, c->d_ref_img.p, out_psnr, nullptr, c->stream);   // synchronises the stream
+        if (rc) return rc;
+    }
+    RR_HIP(c, hipStreamSynchronize(c->stream));
+    Counters h;
+    RR_HIP(c, hipMemcpy(&h, c->lanes[c->last_lane].d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.overflow) RR_HIP(c, hipMemset(c->lanes[c->last_lane].d_sticky.p, 0, sizeof(uint32_t)));
+    if (h.overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
+    if (h.overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
+    return 0;
+}
+}  // namespace
 
 int rr_simulate_material_sets(rr_ctx* c, const float pose[7], const rr_material* sets, int n_sets, size_t n_materials,
                               uint8_t* out_imgs_u8)
@@ -1097,13 +1227,50 @@ int rr_simulate_material_sets(rr_ctx* c, const float pose[7], const rr_material*
     const size_t bytes = (size_t)n_sets * c->cfg.n_cells * c->cfg.n_angles;
     RR_HIP(c, c->d_param_imgs.ensure(bytes));
     int rc = rr_simulate_material_sets_device(c, pose, sets, n_sets, n_materials, c->d_param_imgs.p, c->stream); if (rc) return rc;
-    RR_HIP(c, hipMemcpyAsync(out_imgs_u8, c->d_param_imgs.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    RR_HIP(c, hipStreamSynchronize(c->stream));
-    Counters h;
-    RR_HIP(c, hipMemcpy(&h, c->lanes[c->last_lane].d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (h.overflow) RR_HIP(c, hipMemset(c->lanes[c->last_lane].d_sticky.p, 0, sizeof(uint32_t)));
-    if (h.overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
-    if (h.overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
+    return finish_param_batch(c, n_sets, out_imgs_u8, nullptr, nullptr);
+}
+
+int rr_simulate_param_sets(rr_ctx* c, const float pose[7], const rr_param_set* sets, int n_sets, size_t n_materials,
+                           uint8_t* out_imgs_u8, const uint8_t* ref_img_u8, double* out_psnr)
+{
+    if (!c) return -1;
+    if (!out_imgs_u8 && !(ref_img_u8 && out_psnr)) return fail(c, -3, "rr_simulate_param_sets: neither an image buffer nor a reference image + score buffer");
+    if ((ref_img_u8 == nullptr) != (out_psnr == nullptr)) return fail(c, -3, "rr_simulate_param_sets: ref_img_u8 and out_psnr go together");
+    if (n_sets < 1 || n_sets > RR_MAX_BATCH) return fail(c, -3, "rr_simulate_param_sets: n_sets must be 1..64");
+    RR_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n_sets * c->cfg.n_cells * c->cfg.n_angles;
+    RR_HIP(c, c->d_param_imgs.ensure(bytes));
+    int rc = rr_simulate_param_sets_device(c, pose, sets, n_sets, n_materials, c->d_param_imgs.p, c->stream); if (rc) return rc;
+    return finish_param_batch(c, n_sets, out_imgs_u8, ref_img_u8, out_psnr);
+}
+
+int rr_score_images_device(rr_ctx* c, const uint8_t* d_imgs_u8, int n_images, const uint8_t* d_ref_u8, double* out_psnr,
+                           uint64_t* out_sse, void* stream)
+{
+    if (!c) return -1;
+    if (!c->have_cfg) return fail(c, -2, "rr_set_config has not been called");
+    if (!d_imgs_u8 || !d_ref_u8 || (!out_psnr && !out_sse)) return fail(c, -3, "rr_score_images_device: null buffer");
+    if (n_images < 1 || n_images > 65535) return fail(c, -3, "rr_score_images_device: n_images must be 1..65535");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t npx = (size_t)c->cfg.n_cells * c->cfg.n_angles;
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "sse words");
+    if (c->d_sse.n < (size_t)n_images) { RR_HIP(c, hipStreamSynchronize(s)); RR_HIP(c, c->d_sse.ensure((size_t)n_images)); }
+    RR_HIP(c, hipMemsetAsync(c->d_sse.p, 0, (size_t)n_images * sizeof(uint64_t), s));
+    launch_score(d_imgs_u8, d_ref_u8, npx, n_images, c->d_sse.p, s);
+    RR_HIP(c, hipGetLastError());
+    std::vector<uint64_t> sse((size_t)n_images);
+    RR_HIP(c, hipMemcpyAsync(sse.data(), c->d_sse.p, (size_t)n_images * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    RR_HIP(c, hipStreamSynchronize(s));
+    for (int k = 0; k < n_images; k++) {
+        if (out_sse) out_sse[k] = sse[(size_t)k];
+        if (out_psnr) {
+            // skimage.metrics.peak_signal_noise_ratio for uint8 (scripts/radaray_opti.py:196): data_range 255,
+            // err = mean of the squared differences in f64 (exact here: an integer sum below 2^53), 10 log10(255^2 / err)
+            const double err = (double)sse[(size_t)k] / (double)npx;
+            out_psnr[k] = err > 0.0 ? 10.0 * std::log10((255.0 * 255.0) / err) : INFINITY;
+        }
+    }
     return 0;
 }
 
@@ -1335,6 +1502,21 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
 }
 
 int rr_set_stats_mode(rr_ctx* c, int enable) { if (!c) return -1; c->stats_mode = enable != 0; return 0; }
+
+int rr_get_traversal_shape(rr_ctx* c, uint64_t out[8])
+{
+    if (!c || !out) return -1;
+    RR_HIP(c, hipSetDevice(c->device));
+    RR_HIP(c, hipDeviceSynchronize());
+    std::memset(out, 0, 8 * sizeof(uint64_t));
+    Lane& L = c->lanes[c->last_lane];
+    if (!L.d_counters.p) return 0;
+    Counters h;
+    RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h.n_waves; out[1] = h.it_all; out[2] = h.it_node; out[3] = h.it_leaf; out[4] = h.quad_steps; out[5] = h.max_iters;
+    out[6] = h.nodes; out[7] = h.quad_steps > h.nodes ? h.quad_steps - h.nodes : 0;
+    return 0;
+}
 int rr_set_timing_mode(rr_ctx* c, int enable) { if (!c) return -1; c->timing = enable; return 0; }
 
 int rr_get_kernel_time(rr_ctx* c, const char* kernel, double* total_ms, uint64_t* launches, int reset)

@@ -93,8 +93,16 @@ struct Params {
     const float* smear;          // [smear_w] rescaled weights (RadarCPU.cpp:48-93)
     const float* noise_rnd;      // [noise_rows][n_angles] or null; frame f of a batch reads row f % noise_rows
     int noise_rows;
-    int mat_stride;              // material sets: frame f shades with materials[f * mat_stride + id] (0: one table)
-    int share_first;             // material sets: every frame has the pose of frame 0, pass 0 is traced once
+    int mat_stride;              // parameter sets: frame f shades with materials[f * mat_stride + id] (0: one table)
+    // parameter batch (rr_simulate_param_sets / _material_sets): every "frame" is the SAME pose under its own parameter
+    // set = {material table, beam directions, number of passes}.  Frames with the same beam form a GROUP: pass 0 does not
+    // depend on the materials, so it is traced once per group (for the group's first frame) and every frame of the group
+    // shades those hits; a frame with fewer passes than the launch simply has no live waves in the later ones.
+    int set_mode;                // 0: frames are poses; 1: frames are parameter sets
+    int n_groups;                // set_mode: distinct beam tables = pass-0 trace groups (beam table g at beams + g * n_beam, same for the orders)
+    unsigned char frame_passes[64];   // set_mode: ray-cast passes of frame f (<= n_passes)
+    unsigned char frame_beam[64];     // set_mode: group (= beam table) of frame f
+    unsigned char group_frame[64];    // set_mode: the frame whose segments pass 0 of group g is traced for
     const float* decay;          // [n_cells] expf(-energy_loss * bin range), ambient noise floor
     const float* motion_poses;   // [n_angles][7] per-azimuth Tsm (include_motion) or null
     // frame state
@@ -139,6 +147,9 @@ struct Params {
     const uint4* copy_src; uint4* copy_dst; unsigned long long copy_n16; int copy_blocks;
     int cull_pop;            // later passes / rr_debug_trace: drop stack entries at pop time by their 16-bit distance bound (0: off, RR_CULL_POP=0)
 };
+
+__host__ __device__ inline int passes_of(const Params& P, int frame) { return P.set_mode ? (int)P.frame_passes[frame] : P.n_passes; }
+__host__ __device__ inline int beam_base(const Params& P, int frame) { return P.set_mode ? (int)P.frame_beam[frame] * P.n_beam : 0; }
 
 static_assert(sizeof(Params) <= 4096, "Params is passed by value: HIP kernel arguments are limited to 4 KB");
 

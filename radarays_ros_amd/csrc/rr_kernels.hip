@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         bool live = k < count;
         if (FIRST) {
             // wave w = tile (sample block sb, azimuth block ab) of (16 / A) samples x A neighbouring segments
-            const int ns = P.share_first ? P.n_loc : P.n_seg;
+            const int ns = P.set_mode ? P.n_groups * P.n_loc : P.n_seg;     // parameter sets: one pass 0 per beam group
             const int A = P.pass0_az, lgA = 31 - __builtin_clz(A), Sw = kRaysPerWave >> lgA;
             const int n_ab = (ns + A - 1) >> lgA;
             const int w = blockIdx.x * (kRaysPerBlock / kRaysPerWave) + (rr >> 4), r16 = rr & 15;
@@ -286,15 +286,17 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
             k = sb * Sw + (r16 >> lgA); seg = (ab << lgA) + (r16 & (A - 1));
             live = k < P.n_beam && seg < ns;
             if (!live) { seg = 0; k = 0; }
+            else if (P.set_mode) { const int g = seg / P.n_loc; seg = (int)P.group_frame[g] * P.n_loc + (seg - g * P.n_loc); }   // the group's first frame
         }
         // pass 0 is traced in a sorted order of the beam samples (rows of equal elevation); results are
         // stored under the wave's own index j, so the reference order is untouched
         j = -1;
         V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
         if (live) {
-            j = FIRST ? (int)P.beam_order[k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
+            const int bb = FIRST ? beam_base(P, seg / P.n_loc) : 0;
+            j = FIRST ? (int)P.beam_order[bb + k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
             if (FIRST) {
-                const float4 b = P.beams[j];
+                const float4 b = P.beams[bb + j];
                 dir = { b.x, b.y, b.z };
             } else {
                 const uint32_t slot = P.idx[cur][(size_t)seg * P.cap + j];
@@ -517,16 +519,24 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
     const int cur = pass & 1, nxt = cur ^ 1;
     const int count = FIRST ? P.n_beam : (int)P.count[cur][seg];
     if (j >= count) return;
-    const bool last = (pass == P.n_passes - 1);
+    const int frame = seg / P.n_loc;
+    const int np_f = passes_of(P, frame);          // parameter sets: this frame's own number of passes
+    const bool last = (pass == np_f - 1);
 
     const size_t base2 = (size_t)seg * 2 * P.cap;
     const size_t s0 = base2 + 2 * (size_t)j, s1 = s0 + 1;
+    if (FIRST && pass >= np_f) {                    // a set with n_reflections = 0: no ray is cast, the image stays empty
+        P.cflag[s0] = 0; P.cflag[s1] = 0;
+        const SigRec none = { -1, 0.0f };
+        P.sigtmp[s0] = none; P.sigtmp[s1] = none;
+        return;
+    }
 
     V3 orig = { 0.0f, 0.0f, 0.0f }, dir;
     double energy = 1.0, time = 0.0;   // RadarCPU.cpp:107,112
     uint32_t mat = 0;                   // RadarCPU.cpp:111
     if (FIRST) {
-        const float4 b = P.beams[j];
+        const float4 b = P.beams[beam_base(P, frame) + j];
         dir = { b.x, b.y, b.z };
     } else {
         const uint32_t slot = P.idx[cur][(size_t)seg * P.cap + j];
@@ -542,8 +552,8 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
     uint8_t f0 = 0, f1 = 0;
     SigRec sg0 = { -1, 0.0f }, sg1 = { -1, 0.0f };
 
-    // material sets: all frames share the rays of pass 0, traced once for frame 0
-    const size_t hk = (size_t)((FIRST && P.share_first) ? seg % P.n_loc : seg) * P.cap + j;
+    // parameter sets: the frames of a beam group share the rays of pass 0, traced once for the group's first frame
+    const size_t hk = (size_t)((FIRST && P.set_mode) ? (int)P.group_frame[P.frame_beam[frame]] * P.n_loc + (seg - frame * P.n_loc) : seg) * P.cap + j;
     const uint2 hitrec = P.hit[hk];
     const float range = __uint_as_float(hitrec.x);
     if (range >= 0.0f)   // miss => the wave dies silently (RadarCPU.cpp:252-255)
@@ -582,9 +592,9 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
         if (!ok) {
             atomicOr(&P.counters->overflow, 2u); atomicOr(P.sticky, 2u);
         } else {
-            const float4 m = P.materials[(size_t)(seg / P.n_loc) * P.mat_stride + mat_refr];
+            const float4 m = P.materials[(size_t)frame * P.mat_stride + mat_refr];
             const float v_refraction = (mat != mat_refr) ? m.x : (float)0.3;
-            const double angle_limit = (mat != mat_refr) ? P.mat_limits[(size_t)(seg / P.n_loc) * P.mat_stride + mat_refr] : P.limit_same;
+            const double angle_limit = (mat != mat_refr) ? P.mat_limits[(size_t)frame * P.mat_stride + mat_refr] : P.limit_same;
 
             V3 rdir, tdir; double renergy, tenergy;
             const float incidence_angle = acosf_ref(v_dot(v_neg(dir_in), normal));   // radar_algorithms.h:69 and RadarCPU.cpp:308: one value
@@ -724,7 +734,7 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
         auto fetch = [&](int k, int& c0, int& c1, uint32_t& rp0, uint32_t& rp1) {
             c0 = c1 = 0; rp0 = rp1 = 0xFFFFFFFFu;
             if (k < count) {
-                const uint32_t j = FIRST ? P.beam_order2[k] : P.torder[cur][(size_t)seg * P.cap + k];
+                const uint32_t j = FIRST ? P.beam_order2[beam_base(P, seg / P.n_loc) + k] : P.torder[cur][(size_t)seg * P.cap + k];
                 const size_t sl = base2 + 2 * (size_t)j;
                 const uint2 rp = *reinterpret_cast<const uint2*>(P.refpos + sl);      // both children: one 8-B load (sl is even)
                 const uint8_t f0 = P.cflag[sl], f1 = P.cflag[sl + 1];
@@ -801,7 +811,7 @@ __device__ inline double p_grad2(const double2 g, double x, double y) { return g
 // four (mul, add) gradients and three lerps.
 constexpr int kPerlinRow = 257;
 struct PerlinCol { double v; const double2* t0; const double2* t1; };   // t0: row y, t1: row y - 1
-__device__ inline void perlin_col_table(const unsigned char* pt, const double2* gt, double sy, double2* t0, double2* t1,
+__device__ inline void perlin_col_table(const unsigned char* pt, double sy, double2* t0, double2* t1,
                                         int tid, int n_threads)
 {
     const int Y = (int)floor(sy) & 255;
@@ -809,7 +819,9 @@ __device__ inline void perlin_col_table(const unsigned char* pt, const double2* 
     for (int e = tid; e < 2 * kPerlinRow; e += n_threads) {
         const int row = e >= kPerlinRow ? 1 : 0;
         const int X = (e - row * kPerlinRow) & 255;
-        const double2 g = gt[pt[(pt[X] + Y + row) & 255]];
+        // hash of the lattice corner (X, Y + row, Z = 0): pt[pt[pt[X] + Y + row] + 0]  (image_algorithms.h:80-94); its gradient
+        // is decoded here -- four entries per thread -- instead of through a 4-KB table of the 256 decodes
+        const double2 g = p_grad_coef(pt[pt[(pt[X] + Y + row) & 255]]);
         (row ? t1 : t0)[e - row * kPerlinRow] = make_double2(g.x, g.y * (row ? y - 1 : y));
     }
 }
@@ -863,7 +875,10 @@ void launch_decay_table(float* decay, int n_cells, double resolution, double ene
 // azimuth's signals IN ORDER (f64 add, f32 store like `slice.at<float>() +=`),
 // so the column is bit-reproducible and equal to the sequential CPU loop.
 // ---------------------------------------------------------------------------
-constexpr int kSigChunk = 2048;
+#ifndef RR_SIG_CHUNK
+#define RR_SIG_CHUNK 1024
+#endif
+constexpr int kSigChunk = RR_SIG_CHUNK;          // signals staged per round (8 B each)
 // threads per azimuth column: 4 waves when a launch brings thousands of columns (frame batches: +0.5..1 % against 8 waves;
 // 16 waves lose 12-26 %), 8 waves for the few hundred columns of a single frame (its k_column then takes 80 instead of 91 us)
 
@@ -872,21 +887,26 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
 {
     constexpr int kColWaves = kColThreads / 64;
     extern __shared__ float lds_col[];              // [n_cells] slice
-    // replay phase: the current chunk of signals; noise phase: the four Perlin column tables
-    __shared__ __align__(16) unsigned char s_union[4 * kPerlinRow * sizeof(double2)];
-    static_assert(sizeof(s_union) >= kSigChunk * sizeof(SigRec), "signal chunk must fit");
+    // One LDS region serves the two phases of a column (k_column's workgroups per CU are bounded by LDS: 40 KB each
+    // gave 4, i.e. 4 waves per SIMD for a kernel that waits as long as it issues):
+    //   replay phase: the current chunk of signals, the widened smear weights, the waves' replay lists
+    //   noise phase : the permutation + gradient tables, then the four Perlin column tables built from them
+    constexpr int kWPad = 64;
+    constexpr size_t kReplayBytes = kSigChunk * sizeof(SigRec) + (256 + 2 * kWPad) * sizeof(double) + kColWaves * 64 * sizeof(int2);
+    constexpr size_t kNoiseBytes = 4 * kPerlinRow * sizeof(double2) + 256;
+    constexpr size_t kUnionBytes = kReplayBytes > kNoiseBytes ? kReplayBytes : kNoiseBytes;
+    __shared__ __align__(16) unsigned char s_union[kUnionBytes];
     SigRec* s_sig = reinterpret_cast<SigRec*>(s_union);
     // smear weights, widened once (the replay multiplies in f64), with 64 entries of padding on either side: the 64
     // lanes of a tile that overlaps a signal's window then read 64 CONSECUTIVE doubles (bin - first lies in
     // [-63, W + 62]), conflict-free, and the lanes outside the window are dropped by the select, not by a clamped
     // address (the clamp sent them all to one address on a busy bank: 0.26 conflict cycles per LDS instruction)
-    constexpr int kWPad = 64;
-    __shared__ double s_w[256 + 2 * kWPad];
+    double* s_w = reinterpret_cast<double*>(s_union + kSigChunk * sizeof(SigRec));
+    int2 (*s_list)[64] = reinterpret_cast<int2 (*)[64]>(s_union + kSigChunk * sizeof(SigRec) + (256 + 2 * kWPad) * sizeof(double));   // per wave: overlapping signals of one 64-signal batch
+    double2* s_tab = reinterpret_cast<double2*>(s_union);                                   // noise phase
+    unsigned char* s_perm = reinterpret_cast<unsigned char*>(s_tab + 4 * kPerlinRow);
     __shared__ unsigned long long s_tiles[2];
     __shared__ float s_red[kColWaves];
-    __shared__ unsigned char s_perm[256];
-    __shared__ double2 s_grad[256];
-    __shared__ int2 s_list[kColWaves][64];         // per wave: overlapping signals of one 64-signal batch
     __shared__ int s_wcnt[kColWaves];
 
     const int seg = blockIdx.x;
@@ -911,7 +931,6 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         const int k = i - kWPad;
         s_w[i] = (P.signal_denoising > 0 && k >= 0 && k < W) ? (double)P.smear[k] : 0.0;
     }
-    if (tid < 256) { s_perm[tid] = c_perm[tid]; s_grad[tid] = p_grad_coef(c_perm[tid]); }
     __syncthreads();
 
     int n_valid_last = 0, n_hit_last = 0;
@@ -1049,11 +1068,13 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     const float final_scale = (float)(P.signal_max / (double)max_val);   // :533
     const float rnd = (P.ambient_noise && P.noise_rnd) ? P.noise_rnd[(size_t)((seg / P.n_loc) % P.noise_rows) * P.n_angles + angle_id] : 0.0f;
     PerlinCol pc1 = { 0.0, nullptr, nullptr }, pc2 = pc1;
-    if (P.ambient_noise == 2) {   // the signal chunk is dead (barriers above): its LDS holds the column tables now
-        double2* tab = reinterpret_cast<double2*>(s_union);
+    if (P.ambient_noise == 2) {   // the replay region is dead (barriers above): its LDS holds the noise tables now
+        for (int i = tid; i < 256; i += kColThreads) s_perm[i] = c_perm[i];
+        __syncthreads();
+        double2* tab = s_tab;
         const double sy1 = (double)col * 0.05, sy2 = (double)col * 0.2;
-        perlin_col_table(s_perm, s_grad, sy1, tab, tab + kPerlinRow, tid, kColThreads);
-        perlin_col_table(s_perm, s_grad, sy2, tab + 2 * kPerlinRow, tab + 3 * kPerlinRow, tid, kColThreads);
+        perlin_col_table(s_perm, sy1, tab, tab + kPerlinRow, tid, kColThreads);
+        perlin_col_table(s_perm, sy2, tab + 2 * kPerlinRow, tab + 3 * kPerlinRow, tid, kColThreads);
         pc1 = { p_fade(sy1 - floor(sy1)), tab, tab + kPerlinRow };
         pc2 = { p_fade(sy2 - floor(sy2)), tab + 2 * kPerlinRow, tab + 3 * kPerlinRow };
         __syncthreads();
@@ -1185,6 +1206,52 @@ __global__ __launch_bounds__(256) void k_assemble_u8x4(const uint8_t* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// objective of the parameter optimisation (scripts/radaray_opti.py:170-211): PSNR of a simulated mono8 image against
+// ONE real image.  The device part is the exact integer sum of squared differences per image; the host finishes
+// 10 log10(255^2 / (sse / n)) in f64 like skimage.metrics.peak_signal_noise_ratio.
+// grid (blocks, n_images), block 256; sse[img] must be zero before the launch
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_score(const uint8_t* __restrict__ imgs, const uint8_t* __restrict__ ref, size_t npx,
+                                               unsigned long long* sse)
+{
+    const uint8_t* img = imgs + (size_t)blockIdx.y * npx;
+    unsigned long long acc = 0;
+    const size_t n16 = npx / 16, stride = (size_t)gridDim.x * blockDim.x;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(ref)) & 15u) == 0;
+    size_t done = 0;
+    if (aligned) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+            const uint4 a = reinterpret_cast<const uint4*>(img)[i], b = reinterpret_cast<const uint4*>(ref)[i];
+            const uint32_t aw[4] = { a.x, a.y, a.z, a.w }, bw[4] = { b.x, b.y, b.z, b.w };
+            uint32_t part = 0;                       // 16 x 255^2 fits easily
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int d = (int)((aw[w] >> (8 * k)) & 0xFFu) - (int)((bw[w] >> (8 * k)) & 0xFFu);
+                    part += (uint32_t)(d * d);
+                }
+            acc += part;
+        }
+        done = n16 * 16;
+    }
+    for (size_t i = done + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += stride) {
+        const int d = (int)img[i] - (int)ref[i];
+        acc += (unsigned long long)(d * d);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ unsigned long long s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sse[blockIdx.y], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(64, (npx / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_score, dim3(blocks, (unsigned)n_images), dim3(256), 0, s, imgs, ref, npx, sse);
+}
+
+// ---------------------------------------------------------------------------
 // launchers (called from rr_api.cpp through plain C++ prototypes)
 // ---------------------------------------------------------------------------
 // once per tree upload: builder references (node index / first triangle) -> float4 offsets from the
@@ -1208,7 +1275,7 @@ void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStr
 
 void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const int n_seg = (pass == 0 && P.share_first) ? P.n_loc : P.n_seg;
+    const int n_seg = (pass == 0 && P.set_mode) ? P.n_groups * P.n_loc : P.n_seg;
     // pass 0: one flat sequence of n_seg x n_beam rays; later passes: a row of blocks per segment
     const int A0 = P.pass0_az, Sw0 = kRaysPerWave / A0;
     const size_t waves0 = (size_t)((n_seg + A0 - 1) / A0) * (size_t)((P.n_beam + Sw0 - 1) / Sw0);
@@ -1262,7 +1329,7 @@ void launch_scan(const Params& P, int pass, hipStream_t s)
 void launch_column(const Params& P, hipStream_t s)
 {
     dim3 grid(P.n_seg);
-    const size_t lds = (size_t)P.n_cells * sizeof(float);
+    const size_t lds = (((size_t)P.n_cells * sizeof(float)) + 15) & ~(size_t)15;
     if (P.n_seg >= 1024) hipLaunchKernelGGL(k_column<256>, grid, dim3(256), lds, s, P);
     else hipLaunchKernelGGL(k_column<512>, grid, dim3(512), lds, s, P);
 }

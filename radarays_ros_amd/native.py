@@ -25,7 +25,9 @@ SYMBOLS = [
     "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_ctx",
     "rr_multi_set_mesh", "rr_multi_set_mesh_gpu", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
     "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
-    "rr_multi_simulate_batch_async", "rr_multi_wait", "rr_peek_error_bits_async",
+    "rr_multi_simulate_batch_async", "rr_multi_wait", "rr_peek_error_bits_async", "rr_get_traversal_shape",
+    "rr_cone_dirs", "rr_sample_cone_local", "rr_load_mesh_file", "rr_free_mesh",
+    "rr_simulate_param_sets_device", "rr_simulate_param_sets", "rr_score_images_device",
 ]
 
 
@@ -54,6 +56,15 @@ class RRConfig(C.Structure):
         ("wave_energy_threshold", C.c_float), ("theta_min", C.c_float),
         ("theta_inc", C.c_float), ("range_max", C.c_float),
     ]
+
+
+class RRParamSet(C.Structure):
+    _fields_ = [("materials", C.c_void_p), ("beam_dirs", C.c_void_p), ("n_reflections", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class RRMesh(C.Structure):
+    _fields_ = [("verts", C.POINTER(C.c_float)), ("n_verts", C.c_size_t), ("faces", C.POINTER(C.c_uint32)), ("n_faces", C.c_size_t),
+                ("face_object_id", C.POINTER(C.c_uint32)), ("n_objects", C.c_size_t)]
 
 
 class RRStats(C.Structure):
@@ -156,6 +167,15 @@ def lib():
     L.rr_multi_simulate_batch_async.argtypes = [vp, vp, C.c_int, vp]
     L.rr_multi_wait.argtypes = [vp, vp]
     L.rr_peek_error_bits_async.argtypes = [vp, vp, vp]
+    L.rr_get_traversal_shape.argtypes = [vp, vp]
+    L.rr_simulate_param_sets_device.argtypes = [vp, vp, C.POINTER(RRParamSet), C.c_int, C.c_size_t, vp, vp]
+    L.rr_simulate_param_sets.argtypes = [vp, vp, C.POINTER(RRParamSet), C.c_int, C.c_size_t, vp, vp, vp]
+    L.rr_score_images_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+    L.rr_cone_dirs.argtypes = [C.c_float, C.c_int, C.c_float, vp, vp, C.c_size_t, vp]
+    L.rr_sample_cone_local.argtypes = [C.c_uint32, C.c_float, C.c_size_t, C.c_int, C.c_float, vp]
+    L.rr_load_mesh_file.argtypes = [C.c_char_p, C.POINTER(RRMesh), C.c_char_p, C.c_size_t]
+    L.rr_free_mesh.argtypes = [C.POINTER(RRMesh)]
+    L.rr_free_mesh.restype = None
     for n in SYMBOLS:
         getattr(L, n)
     _LIB = L
@@ -280,6 +300,18 @@ class Context:
                                      None if f32 is None else f32.ctypes.data, C.byref(st)))
         return u8, f32, st.asdict()
 
+    def simulate_into(self, pose, out_u8):
+        """rr_simulate into a preallocated uint8 [n_cells][n_angles] array, no statistics: the call a latency probe times."""
+        p = np.ascontiguousarray(pose, np.float32)
+        self._ck(self._L.rr_simulate(self._h, p.ctypes.data, 0, self.n_angles, out_u8.ctypes.data, None, None))
+
+    def traversal_shape(self):
+        """stats mode: wave-level loop shape of the last frame (rr_get_traversal_shape)."""
+        a = np.zeros(8, np.uint64)
+        self._ck(self._L.rr_get_traversal_shape(self._h, a.ctypes.data))
+        return dict(zip(("waves", "iterations", "node_path_issues", "leaf_path_issues", "live_quad_steps", "max_iterations",
+                         "node_steps", "leaf_steps"), (int(x) for x in a)))
+
     def simulate_columns_device(self, pose, az_begin, az_end, d_cols_u8_ptr, d_cols_f32_ptr=None, stream=None):
         p = np.ascontiguousarray(pose, np.float32)
         self._ck(self._L.rr_simulate_columns_device(self._h, p.ctypes.data, az_begin, az_end,
@@ -334,6 +366,59 @@ class Context:
         out = np.zeros((a.shape[0], n_cells, self.n_angles), dtype=np.uint8)
         self._ck(self._L.rr_simulate_material_sets(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data))
         return out
+
+    @staticmethod
+    def _param_sets(sets):
+        """sets: iterable of dicts {"materials": [n_mat][4] or None, "beam_dirs": [n_beam][3] or None, "n_reflections": int or None}
+        -> (ctypes array, the numpy arrays it points into, n_materials or None)"""
+        keep, n_mat = [], None
+        arr = (RRParamSet * len(sets))()
+        for k, st in enumerate(sets):
+            m = st.get("materials")
+            if m is not None:
+                m = np.ascontiguousarray(np.asarray([(t.astuple() if hasattr(t, "astuple") else t) for t in m], dtype=np.float32))
+                if m.ndim != 2 or m.shape[1] != 4:
+                    raise ValueError("materials of a set must have shape [n_materials][4]")
+                n_mat = m.shape[0] if n_mat is None else n_mat
+                keep.append(m)
+                arr[k].materials = m.ctypes.data
+            b = st.get("beam_dirs")
+            if b is not None:
+                b = np.ascontiguousarray(b, np.float32).reshape(-1, 3)
+                keep.append(b)
+                arr[k].beam_dirs = b.ctypes.data
+            nr = st.get("n_reflections")
+            arr[k].n_reflections = -1 if nr is None else int(nr)
+        return arr, keep, n_mat
+
+    def simulate_param_sets(self, pose, sets, n_materials, ref_u8=None, want_images=True):
+        """rr_simulate_param_sets: one pose, n parameter sets (see _param_sets).  Returns (images uint8
+        [n][n_cells][n_angles] or None, psnr float64 [n] or None against ref_u8)."""
+        arr, keep, n_mat = self._param_sets(sets)
+        p = np.ascontiguousarray(pose, dtype=np.float32)
+        n_cells = self.cfg.n_cells if self.cfg is not None else 1
+        out = np.zeros((len(sets), n_cells, self.n_angles), dtype=np.uint8) if want_images else None
+        psnr = ref = None
+        if ref_u8 is not None:
+            ref = np.ascontiguousarray(ref_u8, np.uint8)
+            if ref.shape != (n_cells, self.n_angles):
+                raise ValueError("reference image must be [n_cells][n_angles] uint8")
+            psnr = np.zeros(len(sets), np.float64)
+        self._ck(self._L.rr_simulate_param_sets(self._h, p.ctypes.data, arr, len(sets), int(n_materials),
+                                                None if out is None else out.ctypes.data,
+                                                None if ref is None else ref.ctypes.data, None if psnr is None else psnr.ctypes.data))
+        return out, psnr
+
+    def simulate_param_sets_device(self, pose, sets, n_materials, d_imgs_ptr, stream=None):
+        arr, keep, _ = self._param_sets(sets)
+        p = np.ascontiguousarray(pose, dtype=np.float32)
+        self._ck(self._L.rr_simulate_param_sets_device(self._h, p.ctypes.data, arr, len(sets), int(n_materials), d_imgs_ptr, stream))
+
+    def score_images_device(self, d_imgs_ptr, n_images, d_ref_ptr, stream=None, want_sse=False):
+        """rr_score_images_device -> psnr float64 [n] (and the exact sums of squared differences uint64 [n])."""
+        psnr = np.zeros(n_images, np.float64); sse = np.zeros(n_images, np.uint64)
+        self._ck(self._L.rr_score_images_device(self._h, d_imgs_ptr, int(n_images), d_ref_ptr, psnr.ctypes.data, sse.ctypes.data, stream))
+        return (psnr, sse) if want_sse else psnr
 
     def simulate_device(self, pose, d_img_ptr, stream=None):
         p = np.ascontiguousarray(pose, np.float32)
@@ -407,6 +492,42 @@ class HostImages:
             self.close()
         except Exception:
             pass
+
+
+def cone_dirs(width_rad, sample_dist, p_in_cone, u_angle, r_variate):
+    """rr_cone_dirs (host only): sample_cone_local's geometry on given variates -> [n][3] float32."""
+    u = np.ascontiguousarray(u_angle, np.float32); r = np.ascontiguousarray(r_variate, np.float32)
+    out = np.zeros((len(u), 3), np.float32)
+    rc = lib().rr_cone_dirs(float(width_rad), int(sample_dist), float(p_in_cone), u.ctypes.data, r.ctypes.data, len(u), out.ctypes.data)
+    if rc:
+        raise RRError("rr_cone_dirs: rc=%d" % rc)
+    return out
+
+
+def sample_cone_local(seed, width_rad, n, sample_dist=2, p_in_cone=0.8):
+    """rr_sample_cone_local (host only): the C twin of beams.sample_cone_local."""
+    out = np.zeros((int(n), 3), np.float32)
+    rc = lib().rr_sample_cone_local(int(seed), float(width_rad), int(n), int(sample_dist), float(p_in_cone), out.ctypes.data)
+    if rc:
+        raise RRError("rr_sample_cone_local: rc=%d" % rc)
+    return out
+
+
+def load_mesh_file(path):
+    """rr_load_mesh_file (host only): PLY / OBJ -> {"verts", "faces", "face_object_id", "n_objects"}."""
+    m = RRMesh()
+    err = C.create_string_buffer(512)
+    rc = lib().rr_load_mesh_file(str(path).encode(), C.byref(m), err, len(err))
+    if rc:
+        raise RRError("%s (rc=%d)" % (err.value.decode(errors="replace"), rc))
+    try:
+        out = {"verts": np.ctypeslib.as_array(m.verts, (m.n_verts, 3)).copy() if m.n_verts else np.zeros((0, 3), np.float32),
+               "faces": np.ctypeslib.as_array(m.faces, (m.n_faces, 3)).copy() if m.n_faces else np.zeros((0, 3), np.uint32),
+               "face_object_id": np.ctypeslib.as_array(m.face_object_id, (m.n_faces,)).copy() if m.n_faces else np.zeros(0, np.uint32),
+               "n_objects": int(m.n_objects)}
+    finally:
+        lib().rr_free_mesh(C.byref(m))
+    return out
 
 
 def partition(n_angles, world, rank):

@@ -4,6 +4,8 @@
 // mono8 image.  No Python, no torch: only the C ABI.
 #include <radarays_ros_amd/RadarHIP.hpp>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 
@@ -19,7 +21,7 @@ static std::vector<T> rd(std::ifstream& f)
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [map.obj]\n", argv[0]); return 2; }
     std::ifstream f(argv[1], std::ios::binary);
     if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
     auto verts = rd<float>(f); auto faces = rd<uint32_t>(f); auto fobj = rd<uint32_t>(f);
@@ -67,6 +69,68 @@ int main(int argc, char** argv)
             multi.updateDynCfg(cm); multi.setMotionPoses(sweep);
             ImagePtr img3 = multi.simulate(42.5);
             if (!img3 || img3->data != img->data) { std::fprintf(stderr, "include_motion sweep differs: %s\n", multi.lastError().c_str()); return 9; }
+        }
+        // the optimiser's evaluation, batched (radaray_opti.py): three RadarParams -- the current ones, a narrower beam with
+        // two passes, other materials with one pass -- as images and as scores against the first image
+        {
+            RadarHIP opt("map", "navtech", verts, faces, fobj, 0);
+            opt.setBeamSeed(7);
+            opt.loadParams(m, std::vector<int>(objmat.begin(), objmat.end()), 0);
+            opt.updateDynCfg(cfg); opt.updateTsm(pose.data());
+            ImagePtr cur = opt.simulate(5.0);
+            if (!cur) { std::fprintf(stderr, "optimiser backend failed: %s\n", opt.lastError().c_str()); return 15; }
+            RadarParams p0 = opt.getParams(), p1 = p0, p2 = p0;
+            p1.model.beam_width = (float)(5.0 * M_PI / 180.0); p1.model.n_reflections = 2;     // as Radar::updateDynCfg converts it
+            for (auto& x : p2.materials) x.ambient *= 0.5f;
+            p2.model.n_reflections = 1;
+            std::vector<ImagePtr> imgs; std::vector<double> psnr;
+            if (!opt.simulateParamSets({ p0, p1, p2 }, 6.0, &imgs, cur.get(), &psnr) || imgs.size() != 3 || psnr.size() != 3) {
+                std::fprintf(stderr, "simulateParamSets: %s\n", opt.lastError().c_str()); return 15;
+            }
+            if (imgs[0]->data != cur->data || !std::isinf(psnr[0]) || !(psnr[1] > 0 && psnr[1] < 100) || !(psnr[2] > 0 && psnr[2] < 100)) {
+                std::fprintf(stderr, "simulateParamSets: set 0 must reproduce the current image (psnr %g %g %g)\n", psnr[0], psnr[1], psnr[2]); return 16;
+            }
+            // set 1 one by one: the same parameters through setParams / updateDynCfg + simulate()
+            RadarModelConfig c1 = cfg; c1.beam_width = 5.0; c1.n_reflections = 2;
+            opt.updateDynCfg(c1);
+            ImagePtr one = opt.simulate(7.0);
+            if (!one || one->data != imgs[1]->data) { std::fprintf(stderr, "simulateParamSets: set 1 differs from the same parameters one by one\n"); return 17; }
+            std::vector<double> only;
+            opt.updateDynCfg(cfg);
+            if (!opt.simulateParamSets({ p0, p1, p2 }, 8.0, nullptr, cur.get(), &only) || only != psnr) { std::fprintf(stderr, "scores without images differ\n"); return 18; }
+        }
+        // dynamic reconfigure of the beam (Radar.cpp:188-218 sets m_resample, RadarCPU.cpp:136-145 re-draws): a backend that
+        // was never given samples draws them itself (rr_sample_cone_local, seeded here), and draws again when beam_width changes
+        {
+            RadarHIP fresh("map", "navtech", verts, faces, fobj, 0);
+            fresh.setBeamSeed(42);
+            fresh.loadParams(m, std::vector<int>(objmat.begin(), objmat.end()), 0);
+            fresh.updateDynCfg(cfg); fresh.updateTsm(pose.data());
+            ImagePtr a = fresh.simulate(1.0);
+            if (!a) { std::fprintf(stderr, "resampling backend failed: %s\n", fresh.lastError().c_str()); return 10; }
+            const std::vector<float> b0 = fresh.beamSamples();
+            if (b0.size() != beams.size()) { std::fprintf(stderr, "resampled %zu values, expected %zu\n", b0.size(), beams.size()); return 10; }
+            uint64_t nb = b0.size();
+            o.write((const char*)&nb, 8); o.write((const char*)b0.data(), (std::streamsize)(nb * sizeof(float)));
+            o.write((const char*)a->data.data(), (std::streamsize)a->data.size());
+            RadarModelConfig narrow = cfg; narrow.beam_width = 6.0;
+            fresh.updateDynCfg(narrow);
+            ImagePtr b = fresh.simulate(2.0);
+            if (!b || fresh.beamSamples() == b0 || b->data == a->data) { std::fprintf(stderr, "beam_width change did not resample\n"); return 11; }
+            fresh.updateDynCfg(narrow);                                  // nothing changed: no re-draw
+            const std::vector<float> b1 = fresh.beamSamples();
+            ImagePtr c2 = fresh.simulate(3.0);
+            if (!c2 || fresh.beamSamples() != b1 || c2->data != b->data) { std::fprintf(stderr, "unchanged config re-drew the beam\n"); return 12; }
+        }
+        // the map file route (rm::import_embree_map, radar_simulator.cpp:149): rr_load_mesh_file gives the arrays back
+        if (argc > 3) {
+            rr_mesh mesh; char err[256];
+            if (rr_load_mesh_file(argv[3], &mesh, err, sizeof(err))) { std::fprintf(stderr, "rr_load_mesh_file: %s\n", err); return 13; }
+            const bool same = mesh.n_verts * 3 == verts.size() && mesh.n_faces * 3 == faces.size() &&
+                              std::equal(verts.begin(), verts.end(), mesh.verts) && std::equal(faces.begin(), faces.end(), mesh.faces) &&
+                              std::equal(fobj.begin(), fobj.end(), mesh.face_object_id);
+            rr_free_mesh(&mesh);
+            if (!same) { std::fprintf(stderr, "rr_load_mesh_file: arrays differ from the scene\n"); return 14; }
         }
         const rr_stats& st = radar.lastStats();
         std::printf("ok %u x %u wave_passes %llu signals %llu\n", img->height, img->width,

@@ -49,4 +49,25 @@ for width, mode in [(50, 20), (35, 12), (100, 40), (10, 3)]:
     mb.append({"width": width, "mode": mode, "normalized": [float(v) for v in y]})
 json.dump({"_provenance": "scripts/maxwell_boltzmann.py:6-10 imported from /root/reference", "cases": mb},
           open(os.path.join(HERE, "pyref_mb.json"), "w"), indent=1)
+# scripts/radaray_beams.py keeps its formulas under `if __name__ == '__main__'`: run it as a script (Agg backend:
+# plt.show() returns at once) with numpy's global generator seeded and read the arrays it leaves behind.  The uniform
+# variates are overwritten by the normal ones (:75), so the draws are repeated here in the script's order (:22,25,75,76).
+import runpy  # noqa: E402
+np.random.seed(20240217)
+g = runpy.run_path(os.path.join(REF, "radaray_beams.py"), run_name="__main__")
+np.random.seed(20240217)
+n = int(g["n_samples"])
+u_uniform = np.random.uniform(0.0, 1.0, size=n)
+np.random.uniform(-np.pi, np.pi, size=n)
+u_normal = np.random.normal(0.0, 1.0, size=n)
+assert np.array_equal(u_normal, g["samples"]) and np.array_equal(u_uniform * g["radius"], g["r_approx"])
+K = 96
+json.dump({"_provenance": "scripts/radaray_beams.py:8-25,75-92 run from /root/reference (runpy, MPLBACKEND=Agg, np.random.seed(20240217)); "
+                          "the first %d of its %d samples; width / radius in degrees as in the script" % (K, n),
+           "width": float(g["width"]), "p_in_cone": float(g["p_in_cone"]), "radius": float(g["radius"]), "z": float(g["z"]),
+           "uniform": [float(x) for x in u_uniform[:K]], "normal": [float(x) for x in u_normal[:K]],
+           "D1_r_approx": [float(x) for x in g["r_approx"][:K]], "D2_r": [float(x) for x in g["r"][:K]],
+           "D3_r1": [float(x) for x in g["r1"][:K]], "D4_r2": [float(x) for x in g["r2"][:K]]},
+          open(os.path.join(HERE, "pyref_beams.json"), "w"), indent=1)
+print("wrote pyref_beams.json (%d samples per law)" % K)
 print("wrote pyref_snell.json (%d cases), pyref_mb.json (%d cases)" % (len(cases), len(mb)))

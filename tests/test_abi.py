@@ -173,3 +173,21 @@ def test_environment_switches_are_documented():
         listed.add("RR_BVH" + suffix)
     assert used - listed == set(), "undocumented: %s" % sorted(used - listed)
     assert listed - used == set(), "documented but unused: %s" % sorted(listed - used)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has_at_once():
+    """`python bench.py --gpus 8` (no launcher): the parent counts devices WITHOUT touching the GPU, and where there are
+    fewer than asked for it exits non-zero with one clear line instead of starting ranks that would fail one by one."""
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("a box with 64 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "--gpus 64 asked for" in r.stderr and "not launched" in r.stderr
+    assert r.stdout.strip() == ""
+    assert time.time() - t0 < 60

@@ -67,14 +67,37 @@ def test_cpp_host_matches_oracle(tmp_path, oracle):
     pose = scenes.default_pose("box12")
     p, o = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
     write_scene(p, s, mats, golden_beams(40), pose, cfg)
-    r = subprocess.run([exe, p, o], capture_output=True, text=True)
+    # the same map as an OBJ file with one `o` group per object: the C++ side loads it with rr_load_mesh_file
+    objp = str(tmp_path / "map.obj")
+    with open(objp, "w") as fo:
+        for v in s["verts"]:
+            fo.write("v %r %r %r\n" % (float(v[0]), float(v[1]), float(v[2])))
+        fid = np.asarray(s["face_object_id"])
+        assert np.all(np.diff(fid.astype(np.int64)) >= 0) and fid[0] == 0       # objects are contiguous runs 0, 1, ...
+        cur = -1
+        for f_, ob in zip(s["faces"], fid):
+            while cur < int(ob):
+                cur += 1
+                fo.write("o object%d\n" % cur)
+            fo.write("f %d %d %d\n" % (f_[0] + 1, f_[1] + 1, f_[2] + 1))
+    r = subprocess.run([exe, p, o, objp], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Couldn't get Transform" in r.stdout           # the null-ImagePtr path was exercised first
     raw = open(o, "rb").read()
     h, w = struct.unpack("<II", raw[:8])
-    img = np.frombuffer(raw[8:], np.uint8).reshape(h, w)
+    img = np.frombuffer(raw[8:8 + h * w], np.uint8).reshape(h, w)
+    # the backend that drew its own beam (seed 42): the directions are beams.py's, its image the oracle's for them
+    off = 8 + h * w
+    nb = struct.unpack("<Q", raw[off:off + 8])[0]
+    drawn = np.frombuffer(raw[off + 8:off + 8 + 4 * nb], np.float32).reshape(-1, 3)
+    img_drawn = np.frombuffer(raw[off + 8 + 4 * nb:off + 8 + 4 * nb + h * w], np.uint8).reshape(h, w)
+    from radarays_ros_amd import beams as B
+    assert drawn.shape == (40, 3) and np.abs(drawn - B.sample_cone_local(10.0, 40, 2, 0.8, seed=42)).max() < 1e-6
     sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=0)
     o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, golden_beams(40), pose)
     d = np.abs(img.astype(int) - o8.astype(int))
     assert (h, w) == (3424, 400) and d.max() <= 1 and (d > 0).mean() < 1e-3
     assert "wave_passes %d" % ost["wave_passes"] in r.stdout
+    d8, _, _ = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, drawn, pose)
+    dd = np.abs(img_drawn.astype(int) - d8.astype(int))
+    assert dd.max() <= 1 and (dd > 0).mean() < 1e-3

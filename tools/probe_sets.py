@@ -1,4 +1,7 @@
-"""Parameter-batch throughput: K material sets per call vs K x (set_materials + simulate_device)."""
+"""Parameter-batch throughput: K material sets per call vs K x (set_materials + simulate_device); and objective
+evaluations/s of the optimiser's full parameter vector (beam_width, n_reflections, materials: rr_simulate_param_sets,
+scores only) against the reference's shape (one set_* + simulate + D2H + numpy PSNR per evaluation).
+usage: probe_sets.py [config id] [passes] [sets per call]"""
 import sys, time, numpy as np, torch
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from radarays_ros_amd import native, params, scenes
@@ -31,4 +34,24 @@ for _ in range(5):
         c.set_materials(ms[k], s["object_materials"], 0); c.simulate_device(pose, imgs[k].data_ptr(), st)
 torch.cuda.synchronize(); dt = time.time() - t0
 print("one by one (set_materials + simulate_device): %.0f images/s" % (5 * K / dt))
+# the optimiser's evaluation (scripts/radaray_opti.py:170-211): K parameter vectors -> K scores, mixed n_reflections and beam widths
+import math
+widths = [6.0, 10.0, 14.0]
+tables = [native.sample_cone_local(40 + i, math.radians(w), 200, 2, 0.8) for i, w in enumerate(widths)]
+psets = [{"materials": sets[k], "beam_dirs": tables[k % 3], "n_reflections": 1 + (k % max(npass, 1))} for k in range(K)]
+real, _, _ = c.simulate(pose)
+for _ in range(3): c.simulate_param_sets(pose, psets, len(mats), ref_u8=real, want_images=False)
+N = 30; t0 = time.time()
+for _ in range(N): _, psnr = c.simulate_param_sets(pose, psets, len(mats), ref_u8=real, want_images=False)
+dt = time.time() - t0
+print("param sets (3 beam widths, 1..%d passes), scores only: %.0f evaluations/s (K = %d per call)" % (max(npass, 1), N * K / dt, K))
+t0 = time.time()
+for _ in range(3):
+    for k in range(K):
+        c.set_materials(ms[k], s["object_materials"], 0); c.set_beam_samples(psets[k]["beam_dirs"])
+        c.set_config(cfg.copy(n_reflections=psets[k]["n_reflections"]))
+        u8, _, _ = c.simulate(pose)
+        err = np.mean((real.astype(np.float64) - u8.astype(np.float64)) ** 2); p1 = 10 * np.log10(255.0 ** 2 / err) if err else np.inf
+dt = time.time() - t0
+print("one by one (set_* + rr_simulate + host PSNR): %.0f evaluations/s" % (3 * K / dt))
 c.close()
