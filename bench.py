@@ -539,6 +539,22 @@ def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
     from oracle import oracle as O
     O.build()
     ncpu = os.cpu_count() or 1
+    # what the process may actually USE: the scheduler affinity and the cgroup's CPU quota (the pool's GPU boxes show 256
+    # hardware threads and grant 16 CPUs' worth of time: cpu.max "1600000 100000" -- the oracle scales linearly to 16
+    # threads there and loses beyond, tools/cpu_scaling.py)
+    usable = ncpu
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+            usable = max(1, min(usable, int(math.ceil(quota))))
+    except (OSError, ValueError):
+        pass
     sc = O.Scene(scene["verts"], scene["faces"], scene["face_object_id"])
     m = [x.astuple() for x in mats]
 
@@ -547,10 +563,9 @@ def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
                               noise_rnd=noise[:400], want_f32=False, n_threads=nt, brdf_model=brdf_model)
         return st["seconds"]
 
-    # the reference parallelises azimuths with OpenMP (RadarCPU.cpp:155); pick the thread
-    # count that is FASTEST on this host (more threads than ~64 lose to false sharing of the
-    # column-strided image writes), so the baseline is not handicapped
-    cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu} | {ncpu})
+    # the reference parallelises azimuths with OpenMP (RadarCPU.cpp:155); pick the thread count that is FASTEST
+    # among those the process can really run, so the baseline is not handicapped
+    cands = sorted({c for c in (4, 8, 16, 32, 64, 128) if c <= usable} | {usable})
     best_nt, best_t = cands[0], float("inf")
     for nt in cands:
         frame(0, nt)
@@ -569,11 +584,13 @@ def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
             break
     med = float(np.median(secs))
     return {"value": round(1.0 / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "host_threads": ncpu, "usable_cpus": usable, "cgroup_cpu_quota": quota,
             "p10": round(1.0 / pct(secs, 0.9), 3), "p90": round(1.0 / pct(secs, 0.1), 3),
             "embree": "unavailable",        # no Embree (nor rmagine) on this box: the in-repo SAH BVH2 stands in
             "sample": "%d full frames of the same workload (16-pose trajectory), median of the "
                       "RadarCPU.cpp:147-550 stopwatch bracket, OpenMP over azimuths, in-repo SAH BVH2 "
-                      "(Embree absent); threads = fastest of %s on this %d-thread host" % (frames, cands, ncpu)}
+                      "(Embree absent); threads = fastest of %s; the host shows %d hardware threads, this process may use %d "
+                      "(affinity / cgroup quota)" % (frames, cands, ncpu, usable)}
 
 
 if __name__ == "__main__":

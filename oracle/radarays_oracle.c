@@ -796,12 +796,25 @@ static int simulate_impl(const orc_scene* scene,
     (void)n_threads;
 #endif
 
-    #pragma omp parallel for schedule(static) num_threads(n_threads) \
+    /* The reference's loop is `#pragma omp parallel for` over the azimuths with everything allocated per azimuth inside
+     * (RadarCPU.cpp:155-187,402) and every thread writing its column straight into the shared image (stride n_angles).
+     * As a BASELINE that stops scaling at 32 threads: heap traffic per azimuth, and 64 neighbouring u8 columns share a
+     * cache line that five threads write.  Same arithmetic, same order, kinder to the memory system: one arena per thread
+     * (wave / signal vectors and the slice, reused over its azimuths), azimuths handed out dynamically (their cost varies
+     * with the scene), columns kept column-major [azimuth][cell] and transposed into the image once at the end. */
+    const size_t n_az = (size_t)(az_end > az_begin ? az_end - az_begin : 0);
+    uint8_t* cols_u8 = out_u8 ? (uint8_t*)malloc(n_az * (size_t)n_cells + 1) : NULL;
+    float* cols_f32 = out_f32 ? (float*)malloc((n_az * (size_t)n_cells + 1) * sizeof(float)) : NULL;
+    #pragma omp parallel num_threads(n_threads) \
         reduction(+:tot_wp,tot_hits,tot_sig,tot_nodes,tot_tris,tot_near) reduction(|:err)
+    {
+    wave_vec waves = { 0 }, waves_new = { 0 };
+    sig_vec signals = { 0 };
+    float* slice = (float*)malloc((size_t)n_cells * sizeof(float) + 4);
+    #pragma omp for schedule(dynamic, 1)
     for (int angle_id = az_begin; angle_id < az_end; angle_id++)    /* :155-156 */
     {
-        wave_vec waves = { 0 }, waves_new = { 0 };
-        sig_vec signals = { 0 };
+        waves.n = 0; waves_new.n = 0; signals.n = 0;
         trav_stats st = { 0, 0 };
 
         /* :106-114, :184  waves = m_waves_start */
@@ -928,7 +941,7 @@ static int simulate_impl(const orc_scene* scene,
         }
 
         /* :402-450 signals -> slice */
-        float* slice = (float*)calloc((size_t)n_cells, sizeof(float));
+        memset(slice, 0, (size_t)n_cells * sizeof(float));
         float max_val = 0.0f;
         for (size_t i = 0; i < signals.n; i++)
         {
@@ -1004,14 +1017,27 @@ static int simulate_impl(const orc_scene* scene,
         }
 
         /* :542  convertTo(col, CV_8UC1) */
-        for (int i = 0; i < n_cells; i++) {
-            if (out_u8) out_u8[(size_t)i * n_angles + col] = orc_saturate_u8(slice[i]);
-            if (out_f32) out_f32[(size_t)i * n_angles + col] = slice[i];
+        {
+            const size_t cb = (size_t)(angle_id - az_begin) * (size_t)n_cells;
+            (void)col;
+            if (cols_u8) for (int i = 0; i < n_cells; i++) cols_u8[cb + i] = orc_saturate_u8(slice[i]);
+            if (cols_f32) memcpy(cols_f32 + cb, slice, (size_t)n_cells * sizeof(float));
         }
 
         tot_nodes += st.nodes; tot_tris += st.tris;
-        free(slice); free(waves.p); free(waves_new.p); free(signals.p);
     }
+    free(slice); free(waves.p); free(waves_new.p); free(signals.p);
+    }
+    /* :457,542  column `col` of the image, all azimuths at once (rows of the image in parallel) */
+    #pragma omp parallel for schedule(static) num_threads(n_threads)
+    for (int i = 0; i < n_cells; i++)
+        for (int angle_id = az_begin; angle_id < az_end; angle_id++) {
+            const int col = (cfg->scroll_image + angle_id) % n_angles;
+            const size_t k = (size_t)(angle_id - az_begin) * (size_t)n_cells + (size_t)i;
+            if (out_u8) out_u8[(size_t)i * n_angles + col] = cols_u8[k];
+            if (out_f32) out_f32[(size_t)i * n_angles + col] = cols_f32[k];
+        }
+    free(cols_u8); free(cols_f32);
 
     const double t_stop = now_s();   /* :550 */
     if (raylog) fclose(raylog);

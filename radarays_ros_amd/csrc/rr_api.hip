@@ -28,7 +28,7 @@ bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t
                     uint32_t* depth_out, uint32_t* stack_need_out, float* inflate_out,
                     std::string& err, hipStream_t stream);
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
-                        float* out_t, uint32_t* out_face, hipStream_t s);
+                        float* out_t, uint32_t* out_face, hipStream_t s, unsigned long long* steps = nullptr);
 void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s);
 void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
@@ -741,12 +741,89 @@ void rr_destroy(rr_ctx* c)
 
 const char* rr_last_error(const rr_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
+namespace {
+
+// the finished host tree -> the ctx's one allocation (nodes, then triangles; references re-encoded as offsets)
+int upload_tree(rr_ctx* c, const Bvh4& bvh)
+{
+    const size_t nn = bvh.nodes.size(), nt = bvh.tris.size();
+    int rc = check_bvh_size(c, nn, nt); if (rc) return rc;
+    // from here on the old tree is being overwritten: no mesh until the new one is complete (an error
+    // return below leaves the context without a mesh, never with a half-written one)
+    c->have_mesh = false;
+    for (Lane& L : c->lanes) L.buf_seg = 0;
+    c->tri_base4 = (uint32_t)(nn * 8);
+    RR_HIP(c, c->d_bvh.ensure(nn * 8 + (nt + 4) * 3));   // +4 triangles: a quad may fetch past a short leaf
+    RR_HIP(c, hipMemcpy(c->d_bvh.p, bvh.nodes.data(), nn * sizeof(Node4), hipMemcpyHostToDevice));
+    if (nt) RR_HIP(c, hipMemcpy(c->d_bvh.p + c->tri_base4, bvh.tris.data(), nt * sizeof(TriRec), hipMemcpyHostToDevice));
+    launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr);
+    RR_HIP(c, hipGetLastError());
+    RR_HIP(c, hipDeviceSynchronize());
+    c->n_nodes = nn; c->n_tris = nt;
+    c->depth = bvh.depth; c->stack_need = bvh.stack_need;
+    c->have_mesh = true;
+    for (Lane& L : c->lanes) L.buf_seg = 0;   // stack geometry may have changed
+    return 0;
+}
+
+// traversal steps (node + leaf) the uploaded tree costs a fixed sample of radar-like rays: origins in the middle of the
+// map's footprint and the lower half of its height, directions within +-5 degrees of horizontal (a radar's beam; reflections
+// off walls stay level) -- a deterministic sample, the same for every candidate tree of a mesh
+int measure_tree_steps(rr_ctx* c, const float lo[3], const float hi[3], double* steps_per_ray)
+{
+    const int n = 16384;
+    std::vector<float> o(3 * (size_t)n), d(3 * (size_t)n);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto u01 = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) * (1.0 / 16777216.0)); };
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 2; k++) o[3 * i + k] = lo[k] + (0.25f + 0.5f * u01()) * (hi[k] - lo[k]);
+        o[3 * i + 2] = lo[2] + (0.05f + 0.45f * u01()) * (hi[2] - lo[2]);
+        const float yaw = 6.2831853f * u01(), el = (u01() - 0.5f) * 0.1745f;
+        d[3 * i] = cosf(el) * cosf(yaw); d[3 * i + 1] = cosf(el) * sinf(yaw); d[3 * i + 2] = sinf(el);
+    }
+    const int stack_lds = (int)std::max<uint32_t>(1, std::min<uint32_t>(c->stack_need, (uint32_t)c->stack_lds_max));
+    const int spill_depth = (int)c->stack_need - stack_lds;
+    DevBuf<float> d_o, d_d; DevBuf<uint32_t> d_spill; DevBuf<unsigned long long> d_steps;
+    hipError_t e = d_o.ensure(3 * (size_t)n);
+    if (e == hipSuccess) e = d_d.ensure(3 * (size_t)n);
+    if (e == hipSuccess) e = d_spill.ensure(spill_depth > 0 ? (size_t)spill_depth * n : 1);
+    if (e == hipSuccess) e = d_steps.ensure(1);
+    if (e == hipSuccess) e = hipMemcpy(d_o.p, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d.p, d.data(), d.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_steps.p, 0, sizeof(unsigned long long));
+    unsigned long long h = 0;
+    if (e == hipSuccess) {
+        Params P; std::memset(&P, 0, sizeof(P));
+        P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
+        P.tri_base4 = c->tri_base4; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
+        P.spill = d_spill.p; P.spill_stride = n; P.stack_lds = stack_lds; P.spill_depth = std::max(0, spill_depth);
+        P.cull_pop = c->cull_pop;
+        launch_debug_trace(P, d_o.p, d_d.p, n, nullptr, nullptr, c->stream, d_steps.p);
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(&h, d_steps.p, sizeof(h), hipMemcpyDeviceToHost);
+    }
+    d_o.release(); d_d.release(); d_spill.release(); d_steps.release();
+    if (e != hipSuccess) return fail(c, -100, std::string("rr_set_mesh (tree choice): ") + hipGetErrorString(e));
+    *steps_per_ray = (double)h / n;
+    return 0;
+}
+
+}  // namespace
+
 int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces, size_t nf,
                 const uint32_t* face_object_id)
 {
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
     Bvh4 bvh; std::string err;
+    // Which tree?  The default -- SAH over references with spatial splits and the vertical weight (rr_bvh.h) -- halves the
+    // traversal steps of maps that mix 0.2 m terrain with 10 m building faces, but on a small regular mesh its few
+    // spatial splits disturb the packing (the 100k-triangle heightfield of config 2: 12.3 steps per ray against 10.9 for
+    // the plain SAH).  Images do not depend on the tree, so for meshes that build in a fraction of a second the choice
+    // is MEASURED: the candidates are uploaded one after the other, each traces the same sample of radar-like rays, the
+    // one with the fewest traversal steps stays.  RR_BVH_CHOOSE=0 (or any RR_BVH_ALPHA / _WZ experiment): default only.
+    const bool choose = nf > 0 && nf <= (size_t)2000000 && !(getenv("RR_BVH_CHOOSE") && atoi(getenv("RR_BVH_CHOOSE")) == 0) &&
+                        !getenv("RR_BVH_ALPHA") && !getenv("RR_BVH_WZ");
     // the builder allocates hundreds of MB and starts threads: whatever it throws (bad_alloc, system_error) stops here
     try {
     if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err)) return fail(c, -4, err);
@@ -755,30 +832,33 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
         BvhOptions plain; plain.sbvh_alpha = -1.0f;
         if (!build_bvh4(verts, nv, faces, nf, face_object_id, bvh, err, 0, &plain)) return fail(c, -4, err);
     }
-    } catch (const std::exception& ex) { return fail(c, -4, std::string("rr_set_mesh: host BVH build failed: ") + ex.what());
-    } catch (...) { return fail(c, -4, "rr_set_mesh: host BVH build failed"); }
     // frames in flight on the lane streams or a caller's stream (all non-blocking: a blocking hipMemcpy
     // does not order against them) still trace the old tree
     RR_HIP(c, hipDeviceSynchronize());
-    {
-        const size_t nn = bvh.nodes.size(), nt = bvh.tris.size();
-        int rc = check_bvh_size(c, nn, nt); if (rc) return rc;
-        // from here on the old tree is being overwritten: no mesh until the new one is complete (an error
-        // return below leaves the context without a mesh, never with a half-written one)
-        c->have_mesh = false;
-        for (Lane& L : c->lanes) L.buf_seg = 0;
-        c->tri_base4 = (uint32_t)(nn * 8);
-        RR_HIP(c, c->d_bvh.ensure(nn * 8 + (nt + 4) * 3));   // +4 triangles: a quad may fetch past a short leaf
-        RR_HIP(c, hipMemcpy(c->d_bvh.p, bvh.nodes.data(), nn * sizeof(Node4), hipMemcpyHostToDevice));
-        if (nt) RR_HIP(c, hipMemcpy(c->d_bvh.p + c->tri_base4, bvh.tris.data(), nt * sizeof(TriRec), hipMemcpyHostToDevice));
-        launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr);
-        RR_HIP(c, hipGetLastError());
-        RR_HIP(c, hipDeviceSynchronize());
+    int rc = upload_tree(c, bvh); if (rc) return rc;
+    if (choose) {
+        float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
+        for (size_t i = 0; i < nv; i++) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], verts[3 * i + k]); hi[k] = std::max(hi[k], verts[3 * i + k]); }
+        double best = 0.0;
+        rc = measure_tree_steps(c, lo, hi, &best); if (rc) return rc;
+        const bool verbose = getenv("RR_BVH_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[rr bvh] tree choice: SAH + spatial splits, vertical weight 0.5: %.2f steps per sample ray\n", best);
+        int kept = 0;
+        for (int cand = 1; cand <= 2; cand++) {
+            BvhOptions o; o.sbvh_alpha = -1.0f; o.vertical_weight = cand == 1 ? 0.5f : 1.0f;
+            Bvh4 alt;
+            if (!build_bvh4(verts, nv, faces, nf, face_object_id, alt, err, 0, &o)) continue;
+            rc = upload_tree(c, alt); if (rc) return rc;
+            double st = 0.0;
+            rc = measure_tree_steps(c, lo, hi, &st); if (rc) return rc;
+            if (verbose) fprintf(stderr, "[rr bvh] tree choice: plain SAH, vertical weight %.1f: %.2f steps per sample ray\n", o.vertical_weight, st);
+            if (st < best * 0.98) { best = st; kept = cand; bvh = std::move(alt); }      // (2 %: do not trade trees over noise in the sample)
+        }
+        if (kept != 2) { rc = upload_tree(c, bvh); if (rc) return rc; }                  // the last candidate uploaded is not the winner
+        if (verbose) fprintf(stderr, "[rr bvh] tree choice: kept candidate %d\n", kept);
     }
-    c->n_nodes = bvh.nodes.size(); c->n_tris = bvh.tris.size();
-    c->depth = bvh.depth; c->stack_need = bvh.stack_need;
-    c->have_mesh = true;
-    for (Lane& L : c->lanes) L.buf_seg = 0;   // stack geometry may have changed
+    } catch (const std::exception& ex) { c->have_mesh = false; return fail(c, -4, std::string("rr_set_mesh: host BVH build failed: ") + ex.what());
+    } catch (...) { c->have_mesh = false; return fail(c, -4, "rr_set_mesh: host BVH build failed"); }
     return 0;
 }
 

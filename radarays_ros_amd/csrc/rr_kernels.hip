@@ -349,9 +349,11 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
 }
 
 // generic rays (tests): one quad per ray
-template <bool CULL>
+// steps != null: the statistics build of the traversal; *steps += the traversal steps (node + leaf) of every ray -- what
+// rr_set_mesh compares candidate trees by
+template <bool CULL, bool STATS>
 __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, const float* origs, const float* dirs, int n,
-                                                               float* out_t, uint32_t* out_face)
+                                                               float* out_t, uint32_t* out_face, unsigned long long* steps)
 {
     extern __shared__ uint32_t lds_stack[];
     const int i = blockIdx.x * kRaysPerBlock + (threadIdx.x >> 2);
@@ -360,11 +362,12 @@ __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, c
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
     const RaySetup R = ray_setup(o, d);
-    const Hit h = traverse<false, true, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
+    const Hit h = traverse<STATS, true, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
     if ((threadIdx.x & 3) == 0) {
-        out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
-        out_face[i] = h.face;
+        if (out_t) out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
+        if (out_face) out_face[i] = h.face;
+        if (STATS) atomicAdd(steps, (unsigned long long)(nt >> 16));     // high half: loop iterations of this ray
     }
 }
 
@@ -906,6 +909,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     double2* s_tab = reinterpret_cast<double2*>(s_union);                                   // noise phase
     unsigned char* s_perm = reinterpret_cast<unsigned char*>(s_tab + 4 * kPerlinRow);
     __shared__ unsigned long long s_tiles[2];
+    __shared__ int s_odd;                             // the chunk holds an echo that is negative or not finite
     __shared__ float s_red[kColWaves];
     __shared__ int s_wcnt[kColWaves];
 
@@ -938,6 +942,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
     for (int c0 = 0; c0 < S; c0 += kSigChunk) {
         const int n_in = min(kSigChunk, S - c0);
         if (tid < 2) s_tiles[tid] = 0ull;
+        if (tid == 2) s_odd = 0;
         // stage the chunk, keeping only the signals that land in the image (RadarCPU.cpp:414), IN ORDER:
         // ballot rank inside the wave + the counts of the waves before it (the per-wave slots of the last
         // pass are half empty -- no multipath echo -- so the replay scans half as many entries)
@@ -946,6 +951,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         // once per wave (one LDS atomic per signal and tile put every lane of a wave on the same two addresses:
         // 10.4 M bank-conflict cycles per launch on the 10M-triangle target, profiles/r02c_t_pmc_summary.json)
         unsigned long long tm0 = 0ull, tm1 = 0ull;
+        bool odd = false;
         for (int r0 = 0; r0 < n_in; r0 += kColThreads) {
             const int i = r0 + tid;
             const int v = c0 + i;
@@ -967,6 +973,7 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
             if (keep) {
                 const int pos = n + before + __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
                 s_sig[pos] = r;
+                odd = odd || !(r.strength >= 0.0f && r.strength < __builtin_inff());
                 int lo = r.cell - mode, hi = r.cell - mode + W - 1;
                 lo = max(lo, 0); hi = min(hi, n_cells - 1);
                 for (int t = lo >> 6; t <= (hi >> 6); t++) { if (t < 64) tm0 |= 1ull << t; else tm1 |= 1ull << (t - 64); }
@@ -975,14 +982,22 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
             __syncthreads();
         }
         for (int off = 32; off > 0; off >>= 1) { tm0 |= __shfl_xor(tm0, off); tm1 |= __shfl_xor(tm1, off); }
-        if (lane == 0) { if (tm0) atomicOr(&s_tiles[0], tm0); if (tm1) atomicOr(&s_tiles[1], tm1); }
+        const bool wave_odd = __ballot(odd) != 0ull;
+        if (lane == 0) { if (tm0) atomicOr(&s_tiles[0], tm0); if (tm1) atomicOr(&s_tiles[1], tm1); if (wave_odd) atomicOr(&s_odd, 1); }
         __syncthreads();
+        // Nearly every chunk holds only finite, non-negative echoes (a negative one needs cos^C with an odd C on a multipath
+        // echo, a NaN a negative cosine under a fractional exponent).  Then (a) a bin never falls, so its running maximum is its
+        // final value and (b) s * 0 is +0, so a lane OUTSIDE a signal's window may add its zero weight (the padded table) and
+        // keeps its value bit for bit: the replay needs neither the window select nor the per-echo fmax -- 7 instead of 11
+        // instructions on the chain that dominates this kernel.  Any other chunk takes the general form.
+        const bool simple = s_odd == 0;
         for (int t = wid; t < n_tiles; t += kColWaves) {
             if (!((s_tiles[t >> 6] >> (t & 63)) & 1ull)) continue;
             const int g = t * 64 + lane;
             const int tlo = t * 64, thi = tlo + 63;
             const bool g_ok = g > 0 && g < n_cells;      // RadarCPU.cpp:424 (bin 0 is never written)
             float acc = (g < n_cells) ? lds_col[g] : 0.0f;
+            const float acc_in = acc;
             // scan 64 signals per step; replay the overlapping ones in order.  A lane outside 0 < g < C
             // gets a bin index that fails every range test (RadarCPU.cpp:424: bin 0 is never written)
             const int gb8 = 8 * g;                           // byte offset of bin g in the f64 weight table
@@ -997,6 +1012,11 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 const float nv = (float)((double)acc + (double)__int_as_float((E).y) * wv);              \
                 acc = (off < W8) ? nv : acc;                                                             \
                 rmax = fmaxf(rmax, acc);       /* `if (slice > max_val) max_val = slice` (NaN never wins) */  \
+            }
+#define RR_REPLAY_S(E)                                                                                   \
+            {                                                                                            \
+                const double wv = *reinterpret_cast<const double*>(wbytes + 8 * kWPad + (gb8 - (E).x));  \
+                acc = (float)((double)acc + (double)__int_as_float((E).y) * wv);                         \
             }
             for (int b0 = 0; b0 < n; b0 += 64) {
                 const int i = b0 + lane;
@@ -1019,11 +1039,19 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     int k = 0;
-                    for (; k + 4 <= cnt; k += 4) {
-                        const int2 e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
-                        RR_REPLAY(e0) RR_REPLAY(e1) RR_REPLAY(e2) RR_REPLAY(e3)
+                    if (simple) {
+                        for (; k + 4 <= cnt; k += 4) {
+                            const int2 e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
+                            RR_REPLAY_S(e0) RR_REPLAY_S(e1) RR_REPLAY_S(e2) RR_REPLAY_S(e3)
+                        }
+                        for (; k < cnt; k++) { const int2 e = list[k]; RR_REPLAY_S(e) }
+                    } else {
+                        for (; k + 4 <= cnt; k += 4) {
+                            const int2 e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
+                            RR_REPLAY(e0) RR_REPLAY(e1) RR_REPLAY(e2) RR_REPLAY(e3)
+                        }
+                        for (; k < cnt; k++) { const int2 e = list[k]; RR_REPLAY(e) }
                     }
-                    for (; k < cnt; k++) { const int2 e = list[k]; RR_REPLAY(e) }
                 } else {
                     while (m) {
                         const int b = __builtin_ctzll(m); m &= m - 1;
@@ -1034,6 +1062,11 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
                 }
             }
 #undef RR_REPLAY
+#undef RR_REPLAY_S
+            if (simple && P.signal_denoising > 0) {
+                acc = g_ok ? acc : acc_in;            // bin 0 (RadarCPU.cpp:424) and the lanes beyond the column took part blindly
+                rmax = fmaxf(rmax, acc);              // non-negative echoes: the running maximum of a bin is where it ends
+            }
             if (g < n_cells) lds_col[g] = acc;
         }
         __syncthreads();
@@ -1358,13 +1391,18 @@ void launch_assemble_f32(const float* cols, float* img, int n_angles, int n_cell
 }
 
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
-                        float* out_t, uint32_t* out_face, hipStream_t s)
+                        float* out_t, uint32_t* out_face, hipStream_t s, unsigned long long* steps)
 {
     dim3 grid((n + kRaysPerBlock - 1) / kRaysPerBlock), block(kTraceThreads);
     const bool cull = kCullPop && P.cull_pop;
     const size_t lds = (size_t)P.stack_lds * kRaysPerBlock * (cull ? 6 : 4);
-    if (cull) hipLaunchKernelGGL(k_debug_trace<true>, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
-    else hipLaunchKernelGGL(k_debug_trace<false>, grid, block, lds, s, P, origs, dirs, n, out_t, out_face);
+    if (steps) {
+        if (cull) hipLaunchKernelGGL((k_debug_trace<true, true>), grid, block, lds, s, P, origs, dirs, n, out_t, out_face, steps);
+        else hipLaunchKernelGGL((k_debug_trace<false, true>), grid, block, lds, s, P, origs, dirs, n, out_t, out_face, steps);
+    } else {
+        if (cull) hipLaunchKernelGGL((k_debug_trace<true, false>), grid, block, lds, s, P, origs, dirs, n, out_t, out_face, steps);
+        else hipLaunchKernelGGL((k_debug_trace<false, false>), grid, block, lds, s, P, origs, dirs, n, out_t, out_face, steps);
+    }
 }
 
 }  // namespace rr

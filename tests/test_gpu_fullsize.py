@@ -158,3 +158,41 @@ def test_config5_per_triangle_materials_8_passes(big, native_lib, oracle):
         assert gst["wave_passes"] == ost["wave_passes"] and gst["signals"] == ost["signals"], (gst, ost)
         d = image_diff(gf[:, az[0]:az[1]], of[:, az[0]:az[1]], g8[:, az[0]:az[1]], o8[:, az[0]:az[1]])
         assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1, d
+
+
+def test_config5_bench_workload_1000_rays_8_passes(big, native_lib, oracle):
+    """configs[4] exactly as `bench.py --workload config5_10M_400x1000_8pass_pertri` runs it ("as 4" = 1000 rays
+    per beam, 8 passes, per-triangle materials, Cook-Torrance lobe, Perlin noise): 1000 x 2^7 exceeds the 65,536-wave
+    clamp of the per-azimuth queue (radarays_mi355.h: max_waves_per_azimuth), so this is the case where the clamp could
+    bite -- it must not (no overflow reported on the whole frame), and two azimuth pairs equal the oracle's twin, whose
+    queues are unbounded: counts exact, mean deviation <= 1e-5."""
+    _, c = big
+    s = scenes.config_scene(5)
+    mats = materials_for(s)
+    c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    c.set_materials(mats, s["object_materials"], 0)
+    cfg = params.kaist_preset(n_reflections=8, n_samples=1000, ambient_noise=2)
+    c.set_config(cfg, 400, brdf_model=1)
+    c.set_beam_samples(golden_beams(1000))
+    rnd = (np.random.RandomState(7).uniform(0, 1, 400) * 1000).astype(np.float32)
+    c.set_noise_offsets(rnd)
+    pose = scenes.default_pose(s["name"])
+    full, _, st = c.simulate(pose)
+    assert st["overflow"] == 0, st
+    assert 400000 * 2 < st["wave_passes"] <= 400000 * 255
+    # the busiest azimuth stays far below the clamp: the frame's wave-passes spread over 400 azimuths and 8 passes
+    assert st["wave_passes"] / 400.0 < 8 * 65536
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=1)
+    for az in ((11, 13), (301, 303)):
+        g8, gf, gst = c.simulate(pose, az[0], az[1], want_f32=True)
+        assert gst["overflow"] == 0
+        assert np.array_equal(g8[:, az[0]:az[1]], full[:, az[0]:az[1]])
+        o8, of, ost = oracle.simulate(sc, mats_tuple(mats), s["object_materials"], cfg, golden_beams(1000), pose,
+                                      noise_rnd=rnd, az_begin=az[0], az_end=az[1], brdf_model=1)
+        assert gst["wave_passes"] == ost["wave_passes"] and gst["hits"] == ost["hits"] and gst["signals"] == ost["signals"], (gst, ost)
+        d = image_diff(gf[:, az[0]:az[1]], of[:, az[0]:az[1]], g8[:, az[0]:az[1]], o8[:, az[0]:az[1]])
+        assert d["mean_dev"] <= 1e-5 and d["u8_max"] <= 1, d
+    # restore the fixture's scene for whoever comes next
+    s4 = scenes.config_scene(4)
+    c.set_mesh(s4["verts"], s4["faces"], s4["face_object_id"])
+    c.set_materials(materials_for(s4), s4["object_materials"], 0)
