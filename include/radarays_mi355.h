@@ -103,7 +103,9 @@ int     rr_abi_version(void);
 /* Replaces rm::import_embree_map (src/radar_simulator.cpp:149): triangle soup
  * + per-face object id (index into object_materials; NULL -> all 0).  Builds
  * the BVH on the host (SAH over references with spatial splits: a face larger than its neighbours may be cut and
- * then has one triangle record per leaf that holds a part of it) and uploads it.  Inputs are copied.  Size limit:
+ * then has one triangle record per leaf that holds a part of it) and uploads it.  For meshes of up to 2M triangles
+ * the tree is CHOSEN by measurement: the plain SAH tree (no spatial splits) is built as well, both trace the same sample
+ * of radar-like rays on the GPU, the one with fewer traversal steps stays (RR_BVH_CHOOSE).  Inputs are copied.  Size limit:
  * 8 x BVH4 nodes + 3 x triangle records < 2^28 (child references are 28-bit offsets), i.e. about 50M triangles; a
  * mesh whose split parts would exceed it is built without spatial splits. */
 int rr_set_mesh(rr_ctx* ctx, const float* verts /*[nv][3]*/, size_t nv,
@@ -412,6 +414,9 @@ void rr_free_mesh(rr_mesh* m);
  * RR_TRACE_STATS          set: rr_get_stats prints the wave-level loop shape of the statistics build
  * RR_BVH_THREADS, RR_BVH_VERBOSE, RR_BVH_ALPHA / _BETA / _BUDGET / _WZ   host builder: threads, phase times, and the
  *                         BvhOptions (csrc/rr_bvh.h) for experiments;  RR_LBVH_NO_SPLIT: GPU builder without split clipping
+ * RR_BVH_CHOOSE (1)       host builder, meshes up to 2M triangles: build the candidates (SAH with spatial splits; plain SAH with
+ *                         vertical weight 0.5 / 1.0), trace one sample of radar-like rays through each, keep the tree with
+ *                         the fewest traversal steps; 0: the default tree only (images are the same whichever tree)
  * RR_MULTI_LOOPBACK (0)   1: rr_create_multi accepts one device several times (tests, see above)
  * RR_MULTI_SLOTS (4)      batches rr_multi keeps in flight (streams + buffer sets per device, 1..8) */
 
