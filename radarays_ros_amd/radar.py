@@ -156,6 +156,31 @@ class RadarHIP:
         return [Image(header=Header(stamp=stamp, frame_id=self.m_sensor_frame), height=u8.shape[0], width=u8.shape[1],
                       encoding="mono8", step=u8.shape[1], data=u8) for u8 in imgs]
 
+    def simulateParamSets(self, sets, stamp=0.0, real=None, want_images=True):
+        """The same action over the optimiser's WHOLE parameter vector (scripts/radaray_opti.py:36-113): `sets` is a list
+        of RadarParams (materials + model.beam_width [rad] / n_samples / n_reflections); one rr_simulate_param_sets call.
+        Beams are drawn like _push() draws them (same seed: equal widths share pass 0).  Returns (images or None,
+        psnr or None) -- with `real` (mono8 [n_cells][400]) the objective values of radaray_opti.py:196."""
+        if not self.updateTsm():
+            print("Couldn't get Transform between sensor and map. Skipping...")
+            return None, None
+        self._push()
+        n_mat, nb = len(self.m_params.materials), self.m_params.model.n_samples
+        ps = []
+        for p in sets:
+            if len(p.materials) != n_mat or p.model.n_samples != nb:
+                raise ValueError("every parameter set needs %d materials and n_samples = %d" % (n_mat, nb))
+            dirs = None
+            if abs(p.model.beam_width - self.m_params.model.beam_width) > 1e-7:
+                dirs = beams.sample_cone_local(np.degrees(p.model.beam_width), nb, self.m_cfg.beam_sample_dist,
+                                               self.m_cfg.beam_sample_dist_normal_p_in_cone, seed=self._beam_seed)
+            ps.append({"materials": [m.astuple() for m in p.materials], "beam_dirs": dirs, "n_reflections": int(p.model.n_reflections)})
+        imgs, psnr = self._ctx.simulate_param_sets(self.Tsm_last, ps, n_mat, ref_u8=real, want_images=want_images)
+        msgs = None if imgs is None else [
+            Image(header=Header(stamp=stamp, frame_id=self.m_sensor_frame), height=u8.shape[0], width=u8.shape[1],
+                  encoding="mono8", step=u8.shape[1], data=u8) for u8 in imgs]
+        return msgs, psnr
+
     @property
     def context(self):
         return self._ctx

@@ -133,3 +133,33 @@ def test_param_sets_are_validated(native_lib, world):
     with pytest.raises(native_lib.RRError, match="go together|neither"):
         c.simulate_param_sets(poses[0], [{}], len(mats), want_images=False)
     c.close()
+
+
+def test_python_twin_simulate_param_sets(native_lib, world):
+    """radar.RadarHIP.simulateParamSets (the Python mirror of the C++ host class): RadarParams in, images + PSNR out;
+    a set equals the same parameters applied through updateDynCfg / loadParams + simulate()."""
+    import copy
+    from radarays_ros_amd import radar
+    from radarays_ros_amd.params import RadarModelConfig
+    s, cfg, mats, noise, poses = world
+    r = radar.RadarHIP(s["verts"], s["faces"], s["face_object_id"], beam_seed=9)
+    r.loadParams(mats, s["object_materials"], 0)
+    dyn = cfg.copy(beam_width=10.0, n_samples=60)
+    r.updateDynCfg(dyn)
+    r.setNoiseOffsets(noise)
+    r.updateTsm(poses[2])
+    cur = r.simulate(1.0)
+    p0 = copy.deepcopy(r.getParams())
+    p1 = copy.deepcopy(p0); p1.model.beam_width = float(np.float32(6.0 * np.pi / 180.0)); p1.model.n_reflections = 2
+    p2 = copy.deepcopy(p0); p2.model.n_reflections = 1
+    for m in p2.materials[1:]:
+        m.ambient *= 0.5
+    msgs, psnr = r.simulateParamSets([p0, p1, p2], stamp=2.0, real=cur.data)
+    assert len(msgs) == 3 and np.array_equal(msgs[0].data, cur.data) and np.isinf(psnr[0])
+    assert msgs[1].header.stamp == 2.0 and msgs[1].encoding == "mono8"
+    assert all(np.isfinite(psnr[1:])) and not np.array_equal(msgs[1].data, msgs[2].data)
+    r.updateDynCfg(dyn.copy(beam_width=6.0, n_reflections=2))
+    one = r.simulate(3.0)
+    assert np.array_equal(one.data, msgs[1].data)
+    none, only = r.simulateParamSets([p0, p1, p2], real=cur.data, want_images=False)
+    assert none is None and np.array_equal(only[1:], psnr[1:])
