@@ -65,10 +65,11 @@ struct KernelTimer {
 }  // namespace
 
 struct Lane {
-    int buf_seg = 0, buf_cap = 0, buf_sigcap = 0, buf_cells = 0;
+    int buf_seg = 0, buf_cap = 0, buf_sigcap = 0, buf_cells = 0, buf_passes = 0;
     DevBuf<float4> d_wA[2], d_wB[2];
     DevBuf<double2> d_wC[2];
-    DevBuf<uint32_t> d_idx[2], d_count[2], d_torder[2], d_refpos, d_sig_count, d_spill;
+    DevBuf<uint32_t> d_idx[2], d_count[2], d_refpos, d_sig_count, d_spill;
+    DevBuf<uint2> d_torder[2];
     DevBuf<uint2> d_hit;
     DevBuf<uint8_t> d_cflag, d_cols_u8;
     DevBuf<SigRec> d_sigtmp, d_sig;
@@ -424,7 +425,7 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     L.spill_stride = (int)threads;
     if (spill_depth > 0) RR_HIP(c, L.d_spill.ensure((size_t)spill_depth * threads));
     else RR_HIP(c, L.d_spill.ensure(1));
-    L.buf_seg = n_seg; L.buf_cap = cap; L.buf_sigcap = sigcap; L.buf_cells = g.n_cells;
+    L.buf_seg = n_seg; L.buf_cap = cap; L.buf_sigcap = sigcap; L.buf_cells = g.n_cells; L.buf_passes = std::max(1, g.n_reflections);
     return 0;
 }
 
@@ -438,8 +439,15 @@ int prepare_lane(rr_ctx* c, Lane& L, int n_seg, bool want_f32 = false)
     const rr_config g = eff_config(c);      // (a parameter batch may ask for more passes than the config)
     const int n_beam = (int)(c->beams.size() / 3);
     const int cap = wave_capacity(g, n_beam);
-    const bool fits = L.buf_seg >= n_seg && cap == L.buf_cap && g.n_cells == L.buf_cells &&
-                      signal_capacity(g, n_beam, cap) == L.buf_sigcap &&
+    const int sigcap = signal_capacity(g, n_beam, cap);
+    // a parameter batch (its sets bring their own numbers of passes, so the nominal capacity changes from call to call)
+    // also runs in buffers that are LARGER than it needs: the kernels take every stride from the lane (Params::cap), and
+    // with the default capacity nothing can overflow that would not have overflowed the nominal one.  Ordinary frames keep
+    // the exact layout (a user-lowered max_waves_per_azimuth must be reported when exceeded).
+    const bool roomy = c->passes_override >= 0 && c->cfg.max_waves_per_azimuth <= 0 && L.buf_cap >= cap && L.buf_sigcap >= sigcap &&
+                       L.buf_passes >= g.n_reflections;
+    const bool fits = L.buf_seg >= n_seg && g.n_cells == L.buf_cells &&
+                      ((cap == L.buf_cap && sigcap == L.buf_sigcap && L.buf_passes >= g.n_reflections) || roomy) &&
                       (!want_f32 || (L.d_cols_f32.p && L.d_cols_f32.n >= (size_t)L.buf_seg * g.n_cells));
     if (fits) return 0;
     RR_HIP(c, hipDeviceSynchronize());

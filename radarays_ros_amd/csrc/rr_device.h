@@ -109,7 +109,7 @@ struct Params {
     WaveBuf waves[2];            // [n_seg][2*cap] child slots, ping-pong by pass parity
     uint32_t* idx[2];            // [n_seg][cap] live slot list
     uint32_t* count[2];          // [n_seg]
-    uint32_t* torder[2];         // [n_seg][cap] trace slot -> position in idx (coherent order, inherited from pass 0)
+    uint2* torder[2];            // [n_seg][cap] trace position -> (position in idx, child slot): the order the rays of a later pass are TRACED in (coherent order, inherited from pass 0); the slot rides along so that k_trace reaches its wave with one dependent load less
     uint32_t* refpos;            // [n_seg][2*cap] child slot -> its position in the next pass' idx
     uint8_t* cflag;              // [n_seg][2*cap] child alive flags (+ bit2 on slot 2j: hit)
     SigRec* sigtmp;              // [n_seg][2*cap] per-wave signal slots (path, air)

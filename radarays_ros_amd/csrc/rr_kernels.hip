@@ -294,12 +294,14 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         V3 orig = { 0.0f, 0.0f, 0.0f }, dir = { 1.0f, 0.0f, 0.0f };
         if (live) {
             const int bb = FIRST ? beam_base(P, seg / P.n_loc) : 0;
-            j = FIRST ? (int)P.beam_order[bb + k] : (int)P.torder[cur][(size_t)seg * P.cap + k];
+            uint2 tj = make_uint2(0u, 0u);
+            if (!FIRST) tj = P.torder[cur][(size_t)seg * P.cap + k];
+            j = FIRST ? (int)P.beam_order[bb + k] : (int)tj.x;
             if (FIRST) {
                 const float4 b = P.beams[bb + j];
                 dir = { b.x, b.y, b.z };
             } else {
-                const uint32_t slot = P.idx[cur][(size_t)seg * P.cap + j];
+                const uint32_t slot = tj.y;           // = idx[cur][j], carried by the trace order (k_scan)
                 const size_t w = (size_t)seg * 2 * P.cap + slot;
                 const float4 A = P.waves[cur].A[w], B = P.waves[cur].B[w];
                 orig = { A.x, A.y, A.z };
@@ -734,26 +736,28 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
             }
         }
         int placed0 = 0, placed1 = 0;
-        auto fetch = [&](int k, int& c0, int& c1, uint32_t& rp0, uint32_t& rp1) {
-            c0 = c1 = 0; rp0 = rp1 = 0xFFFFFFFFu;
+        auto fetch = [&](int k, int& c0, int& c1, uint32_t& rp0, uint32_t& rp1, uint32_t& jp) {
+            c0 = c1 = 0; rp0 = rp1 = 0xFFFFFFFFu; jp = 0;
             if (k < count) {
-                const uint32_t j = FIRST ? P.beam_order2[beam_base(P, seg / P.n_loc) + k] : P.torder[cur][(size_t)seg * P.cap + k];
+                const uint32_t j = FIRST ? P.beam_order2[beam_base(P, seg / P.n_loc) + k] : P.torder[cur][(size_t)seg * P.cap + k].x;
                 const size_t sl = base2 + 2 * (size_t)j;
                 const uint2 rp = *reinterpret_cast<const uint2*>(P.refpos + sl);      // both children: one 8-B load (sl is even)
                 const uint8_t f0 = P.cflag[sl], f1 = P.cflag[sl + 1];
                 if (f0 & 1) { rp0 = rp.x; c0 = rp0 != 0xFFFFFFFFu; }
                 if (f1 & 1) { rp1 = rp.y; c1 = rp1 != 0xFFFFFFFFu; }
+                jp = j;
             }
         };
-        int c0n, c1n; uint32_t rp0n, rp1n;
-        fetch((int)threadIdx.x, c0n, c1n, rp0n, rp1n);
+        int c0n, c1n; uint32_t rp0n, rp1n, jpn;
+        fetch((int)threadIdx.x, c0n, c1n, rp0n, rp1n, jpn);
         for (int b = 0; b < count; b += 256) {
-            const int c0 = c0n, c1 = c1n; const uint32_t rp0 = rp0n, rp1 = rp1n;
-            fetch(b + 256 + (int)threadIdx.x, c0n, c1n, rp0n, rp1n);
+            const int c0 = c0n, c1 = c1n; const uint32_t rp0 = rp0n, rp1 = rp1n, jp = jpn;
+            fetch(b + 256 + (int)threadIdx.x, c0n, c1n, rp0n, rp1n, jpn);
             int tot;
             const int pre = block_excl_scan(c0 | (c1 << 10), tot, lds);
-            if (c0) P.torder[nxt][(size_t)seg * P.cap + placed0 + (pre & 1023)] = rp0;
-            if (c1) P.torder[nxt][(size_t)seg * P.cap + n_refl_placed + placed1 + ((pre >> 10) & 1023)] = rp1;
+            // (position in the next pass' list, child slot = 2 x the parent's position [+ 1]): the slot saves k_trace the idx lookup
+            if (c0) P.torder[nxt][(size_t)seg * P.cap + placed0 + (pre & 1023)] = make_uint2(rp0, 2u * jp);
+            if (c1) P.torder[nxt][(size_t)seg * P.cap + n_refl_placed + placed1 + ((pre >> 10) & 1023)] = make_uint2(rp1, 2u * jp + 1u);
             placed0 += tot & 1023; placed1 += (tot >> 10) & 1023;
         }
     }

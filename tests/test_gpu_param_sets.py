@@ -163,3 +163,27 @@ def test_python_twin_simulate_param_sets(native_lib, world):
     assert np.array_equal(one.data, msgs[1].data)
     none, only = r.simulateParamSets([p0, p1, p2], real=cur.data, want_images=False)
     assert none is None and np.array_equal(only[1:], psnr[1:])
+
+
+def test_param_batches_of_changing_depth_on_one_context(native_lib, world):
+    """An optimiser's calls bring different largest numbers of passes from one call to the next: the lane's wave queues
+    are sized by the largest seen and re-used for shallower batches (no re-allocation per call), ordinary frames in
+    between go back to the exact layout -- every image still equals the one-by-one path."""
+    s, cfg, mats, noise, poses = world
+    base = golden_beams(60)
+    c, ref = _ctx(native_lib, world, base), _ctx(native_lib, world, base)
+    m0 = np.array(mats_tuple(mats), np.float32)
+
+    def check(depths, pose):
+        sets = [{"materials": m0, "n_reflections": d} for d in depths]
+        imgs, _ = c.simulate_param_sets(pose, sets, len(mats))
+        for k, d in enumerate(depths):
+            ref.set_config(cfg.copy(n_reflections=d), 400)
+            assert np.array_equal(imgs[k], ref.simulate(pose)[0]), (depths, k)
+    for lane_round in range(2):                # 4 frame lanes: every lane sees a deep batch, then shallower ones
+        for depths in ([5, 1], [2, 2, 0], [3], [4, 1, 2]):
+            check(depths, poses[lane_round])
+        ref.set_config(cfg, 400)
+        assert np.array_equal(c.simulate(poses[3])[0], ref.simulate(poses[3])[0])
+        check([1, 3], poses[2])
+    c.close(); ref.close()
