@@ -415,12 +415,18 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
         }
     if (!m->loopback) {
         RRM_TRY_NCCL(g_rccl.GroupStart());
+        ncclResult_t gr = 0; hipError_t ge = hipSuccess;          // a failure inside the group still has to close the group
         for (const Piece& p : pieces) {
-            if (p.dev == 0) continue;
-            RRM_TRY_NCCL(g_rccl.Send(S.block[(size_t)p.dev].p + p.so, p.bytes, kNcclUint8, 0, m->comms[(size_t)p.dev], S.streams[(size_t)p.dev]));
-            RRM_TRY_NCCL(g_rccl.Recv(S.gathered.p + p.ro, p.bytes, kNcclUint8, p.dev, m->comms[0], S.streams[0]));
+            if (p.dev == 0 || gr != 0 || ge != hipSuccess) continue;
+            // (one thread drives every device: the current device follows the communicator a call is made on)
+            ge = hipSetDevice(m->devices[(size_t)p.dev]);
+            if (ge == hipSuccess) gr = g_rccl.Send(S.block[(size_t)p.dev].p + p.so, p.bytes, kNcclUint8, 0, m->comms[(size_t)p.dev], S.streams[(size_t)p.dev]);
+            if (ge == hipSuccess && gr == 0) ge = hipSetDevice(m->devices[0]);
+            if (ge == hipSuccess && gr == 0) gr = g_rccl.Recv(S.gathered.p + p.ro, p.bytes, kNcclUint8, p.dev, m->comms[0], S.streams[0]);
         }
-        RRM_TRY_NCCL(g_rccl.GroupEnd());
+        const ncclResult_t ger = g_rccl.GroupEnd();
+        if (ge != hipSuccess) return fail_drained(m, -100, std::string("hipSetDevice (collective): ") + hipGetErrorString(ge));
+        if (gr != 0 || ger != 0) return fail_drained(m, -101, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(gr != 0 ? gr : ger));
     }
     // 3. root: transpose into mono8 images, copy to the caller's host buffer
     RRM_TRY_HIP(hipSetDevice(m->devices[0]));
