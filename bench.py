@@ -169,6 +169,11 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything in this
         # process touches the GPU (the parent only counts devices and waits for the child)
         raise SystemExit(self_launch(args.gpus))
+    # stdout carries ONE line, the JSON line: whatever else writes to file descriptor 1 from here on -- RCCL prints a
+    # five-line version banner there when a communicator is made, from C, flushed at exit, i.e. AFTER the line -- goes to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if world != args.gpus:
         args.gpus = world
 
@@ -531,7 +536,8 @@ def main():
     if world > 1 or args.force_slots:
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
 
 def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
