@@ -149,6 +149,9 @@ bool load_ply(const std::string& path, std::vector<float>& verts, std::vector<ui
 {
     std::ifstream f(path, std::ios::binary);
     if (!f) { err = path + ": cannot open"; return false; }
+    f.seekg(0, std::ios::end);
+    const size_t file_bytes = (size_t)std::max<std::streamoff>(0, f.tellg());     // no element count of the header is trusted beyond it
+    f.seekg(0, std::ios::beg);
     std::string line;
     std::getline(f, line);
     while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
@@ -179,6 +182,7 @@ bool load_ply(const std::string& path, std::vector<float>& verts, std::vector<ui
         }
         if (is_v) {
             if (ix < 0 || iy < 0 || iz < 0) { err = path + ": vertex element without x / y / z"; return false; }
+            if (e.count > file_bytes) { err = path + ": vertex count exceeds the file"; return false; }     // (an element takes at least a byte)
             verts.reserve(3 * e.count); have_verts = true;
         }
         std::vector<long long> idx;
@@ -197,6 +201,7 @@ bool load_ply(const std::string& path, std::vector<float>& verts, std::vector<ui
                     else if (!ply_read(f, p.count_type, big, cnt)) { err = path + ": truncated PLY body"; return false; }
                     const bool want = is_f && (p.name == "vertex_indices" || p.name == "vertex_index");
                     if (want) idx.clear();
+                    if (!(cnt >= 0.0 && cnt <= (double)file_bytes)) { err = path + ": list length exceeds the file"; return false; }
                     for (long long j = 0; j < (long long)cnt; j++) {
                         double v = 0.0;
                         if (ascii) { if (!(f >> v)) { err = path + ": truncated PLY body"; return false; } }

@@ -1,0 +1,87 @@
+// rr_host.cpp (the host-only pieces of the C ABI: beam sampler, PLY / OBJ map loader) under AddressSanitizer + UBSan:
+// well-formed files, then thousands of damaged ones (truncated, bytes flipped, counts inflated) -- the loader parses files
+// from disk, it must fail with an error code, never with a crash or an out-of-bounds access.
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -I include tests/cpp/host_side_check.cpp radarays_ros_amd/csrc/rr_host.cpp -o /tmp/hsc && /tmp/hsc /tmp
+#include <radarays_mi355.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+static uint64_t g_s = 0x243F6A8885A308D3ull;
+static uint32_t rnd() { g_s = g_s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(g_s >> 33); }
+static void put(const std::string& path, const std::string& bytes) { std::ofstream f(path, std::ios::binary); f.write(bytes.data(), (std::streamsize)bytes.size()); }
+
+int main(int argc, char** argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    int fails = 0;
+    // ---- beam sampler ------------------------------------------------------------------------------------------
+    {
+        std::vector<float> d(3 * 1000);
+        for (int dist = 0; dist < 4; dist++) {
+            if (rr_sample_cone_local(42, 0.17f, 1000, dist, 0.8f, d.data())) { std::printf("sampler dist %d failed\n", dist); fails++; }
+            for (int i = 0; i < 1000; i++) {
+                const float n = std::sqrt(d[3 * i] * d[3 * i] + d[3 * i + 1] * d[3 * i + 1] + d[3 * i + 2] * d[3 * i + 2]);
+                if (!(std::fabs(n - 1.0f) < 1e-5f)) { std::printf("direction %d of dist %d is not a unit vector\n", i, dist); fails++; break; }
+            }
+        }
+        if (rr_sample_cone_local(1, 0.1f, 4, 7, 0.8f, d.data()) == 0 || rr_cone_dirs(0.1f, -1, 0.8f, d.data(), d.data(), 1, d.data()) == 0) { std::printf("bad sample_dist accepted\n"); fails++; }
+        if (rr_sample_cone_local(1, 0.1f, 0, 2, 0.8f, nullptr) != 0) { std::printf("n = 0 refused\n"); fails++; }
+        std::printf("sampler: %s\n", fails ? "FAILED" : "ok");
+    }
+    // ---- well-formed files -------------------------------------------------------------------------------------
+    const std::string ply_ascii = "ply\nformat ascii 1.0\ncomment x\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n"
+                                  "element face 2\nproperty list uchar int vertex_indices\nend_header\n0 0 0 1\n1 0 0 2\n1 1 0 3\n0 1 0 4\n4 0 1 2 3\n3 0 2 3\n";
+    std::string ply_bin = "ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty double x\nproperty double y\nproperty double z\n"
+                          "element face 1\nproperty list uchar uint vertex_index\nend_header\n";
+    { const double v[9] = { 0, 0, 0, 1, 0, 0, 0, 1, 0 }; ply_bin.append((const char*)v, sizeof(v)); const unsigned char c = 3; ply_bin.push_back((char)c);
+      const uint32_t idx[3] = { 0, 1, 2 }; ply_bin.append((const char*)idx, sizeof(idx)); }
+    const std::string obj = "# c\no a\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\ng b\nf -4//1 -3//1 -2//1\nvn 0 0 1\n";
+    struct Case { const char* name; std::string ext, bytes; size_t nv, nf; } good[3] = {
+        { "ply ascii", ".ply", ply_ascii, 4, 3 }, { "ply binary", ".ply", ply_bin, 3, 1 }, { "obj", ".obj", obj, 4, 3 } };
+    for (const Case& c : good) {
+        const std::string p = dir + "/hsc_good" + c.ext;
+        put(p, c.bytes);
+        rr_mesh m; char err[256] = "";
+        const int rc = rr_load_mesh_file(p.c_str(), &m, err, sizeof(err));
+        const bool ok = rc == 0 && m.n_verts == c.nv && m.n_faces == c.nf;
+        std::printf("%s: %s %s\n", c.name, ok ? "ok" : "FAILED", err);
+        fails += !ok;
+        rr_free_mesh(&m); rr_free_mesh(&m);          // twice: must be harmless
+    }
+    // ---- damaged files: error code or a mesh whose indices are in range, never a crash ----------------------------
+    size_t n_ok = 0, n_err = 0;
+    for (int it = 0; it < 6000; it++) {
+        const Case& c = good[it % 3];
+        std::string b = c.bytes;
+        const int kind = (int)(rnd() % 4);
+        if (kind == 0) b.resize(rnd() % (b.size() + 1));                                        // truncated
+        else if (kind == 1) for (int k = 0; k < 1 + (int)(rnd() % 4); k++) b[rnd() % b.size()] = (char)(rnd() & 0xFF);   // bytes flipped
+        else if (kind == 2) { const size_t at = rnd() % b.size(); b.insert(at, std::to_string(rnd())); }   // digits inserted (inflated counts / indices)
+        else { const size_t at = rnd() % b.size(), n = rnd() % 16; b.erase(at, std::min(n, b.size() - at)); }  // bytes removed
+        const std::string p = dir + "/hsc_bad" + c.ext;
+        put(p, b);
+        rr_mesh m; char err[256] = "";
+        const int rc = rr_load_mesh_file(p.c_str(), &m, err, sizeof(err));
+        if (rc == 0) {
+            n_ok++;
+            for (size_t i = 0; i < 3 * m.n_faces; i++) if (m.faces[i] >= m.n_verts) { std::printf("iteration %d: index out of range in an accepted mesh\n", it); fails++; break; }
+            for (size_t i = 0; i < m.n_faces; i++) if (m.face_object_id[i] >= m.n_objects) { std::printf("iteration %d: object id out of range\n", it); fails++; break; }
+            rr_free_mesh(&m);
+        } else {
+            n_err++;
+            if (m.verts || m.faces || m.face_object_id || !err[0]) { std::printf("iteration %d: a failed load left pointers or no message\n", it); fails++; }
+        }
+    }
+    std::printf("damaged files: %zu accepted (indices in range), %zu refused: %s\n", n_ok, n_err, fails ? "FAILED" : "ok");
+    char e2[8]; rr_mesh m2;
+    if (rr_load_mesh_file((dir + "/does_not_exist.ply").c_str(), &m2, e2, sizeof(e2)) == 0 || std::strlen(e2) >= sizeof(e2)) { std::printf("short error buffer mishandled\n"); fails++; }
+    if (rr_load_mesh_file(nullptr, &m2, nullptr, 0) == 0) { std::printf("null path accepted\n"); fails++; }
+    std::printf("%s\n", fails ? "FAILED" : "all: ok");
+    return fails ? 1 : 0;
+}
