@@ -252,8 +252,8 @@ int rr_multi_set_motion_poses(rr_multi* m, const float* poses, size_t n)
 }
 
 // ---- the data plan of one call: pure arithmetic, exported so that it can be checked without a GPU ------------
-// equal blocks : every device all-gathers `bytes_per_device`; device r's block lands at r * bytes_per_device of the
-//                gathered buffer, laid out [device][frame][n_loc][n_cells]
+// equal blocks : device r's whole block buffer (`bytes_per_device`) travels as ONE piece and lands at r * bytes_per_device
+//                of the root's buffer, laid out [device][frame][n_loc][n_cells]
 // ragged blocks: device r sends, for every frame f, the n_loc_r * n_cells bytes at send_off[r][f] of ITS block buffer
 //                ([frame][n_loc_r][n_cells]) to the root, which receives them at recv_off[r][f] of [frame][n_angles][n_cells]
 int rr_multi_plan(int n_angles, int n_cells, int n_devices, int n_frames, int* equal_blocks, size_t* bytes_per_device,
