@@ -49,10 +49,42 @@ for width, mode in [(50, 20), (35, 12), (100, 40), (10, 3)]:
     mb.append({"width": width, "mode": mode, "normalized": [float(v) for v in y]})
 json.dump({"_provenance": "scripts/maxwell_boltzmann.py:6-10 imported from /root/reference", "cases": mb},
           open(os.path.join(HERE, "pyref_mb.json"), "w"), indent=1)
+# Fresnel ENERGIES: scripts/reflections/fresnel.py:99-165 computes rs / rp / Reff / Teff inside the render() closure of its
+# __main__ block (interactive tool).  Run it as a script under the Agg backend, then drive it through its own slider
+# callbacks (update_n1 / update_n2 / update_inc_angle, module globals after the run); render() stores Reff and Teff as the
+# alpha of its two line artists -- read back exactly, no parsing.  Python's n1 is "upper medium (or v2)", n2 "lower (or
+# v1)": the C++ convention n1 := v2, n2 := v1 (radar_algorithms.h:62-63).  Cases whose Reff leaves [0, 1] (v2 = 0: the
+# artist refuses the alpha) are left to the survey's known answers.
+import contextlib  # noqa: E402
+import io  # noqa: E402
+import runpy  # noqa: E402
+with contextlib.redirect_stdout(io.StringIO()):
+    gf = runpy.run_path(os.path.join(REF, "reflections", "fresnel.py"), run_name="__main__")
+energy = []
+with contextlib.redirect_stdout(io.StringIO()):
+    def drive(fn, val):          # (a render whose Reff rounds to 1 + 1e-15 makes the artist raise: that case is skipped)
+        try:
+            gf[fn](val)
+            return True
+        except ValueError:
+            return False
+    for v2 in [0.03, 0.05, 0.1, 0.15, 0.2, 0.25, 0.3, 0.45]:
+        drive("update_inc_angle", 30.0)
+        drive("update_n1", v2)
+        drive("update_n2", 0.3)
+        for theta_deg in [0.0, 2.0, 5.0, 10.0, 20.0, 30.0, 45.0, 60.0, 75.0, 85.0, 89.0]:
+            if drive("update_inc_angle", theta_deg):
+                energy.append({"theta_deg": theta_deg, "v1": 0.3, "v2": v2,
+                               "Reff": float(gf["line_refl"].get_alpha()), "Teff": float(gf["line_refr"].get_alpha())})
+json.dump({"_provenance": "scripts/reflections/fresnel.py:99-165 (render(): rs, rp, Reff, Teff) run from /root/reference via runpy under "
+                          "MPLBACKEND=Agg and driven through its slider callbacks; surface normal (0, 1), ray (sin a, -cos a); "
+                          "f64 throughout (the C++ narrows the angles to f32: compare at 1e-6)", "cases": energy},
+          open(os.path.join(HERE, "pyref_fresnel_energy.json"), "w"), indent=1)
+print("wrote pyref_fresnel_energy.json (%d cases)" % len(energy))
+
 # scripts/radaray_beams.py keeps its formulas under `if __name__ == '__main__'`: run it as a script (Agg backend:
 # plt.show() returns at once) with numpy's global generator seeded and read the arrays it leaves behind.  The uniform
 # variates are overwritten by the normal ones (:75), so the draws are repeated here in the script's order (:22,25,75,76).
-import runpy  # noqa: E402
 np.random.seed(20240217)
 g = runpy.run_path(os.path.join(REF, "radaray_beams.py"), run_name="__main__")
 np.random.seed(20240217)
