@@ -104,6 +104,8 @@ def lib():
     L.orc_quantile.argtypes = [C.c_float]
     L.orc_wave_move.argtypes = [fp, fp, C.POINTER(C.c_double), C.c_double, C.c_double]
     L.orc_sample_cone_local.argtypes = [C.c_float, C.c_int, C.c_int, C.c_float, fp, fp, fp]
+    L.orc_noise_amplitude.restype = C.c_float
+    L.orc_noise_amplitude.argtypes = [C.c_float, C.c_float, C.c_double, C.c_double]
     L.orc_cone_radius.restype = C.c_float
     L.orc_cone_radius.argtypes = [C.c_float, C.c_int, C.c_float, C.c_float]
     L.orc_saturate_u8.restype = C.c_uint8
@@ -177,6 +179,10 @@ def sample_cone_local(width_rad, sample_dist, p_in_cone, u_angle, r_variate):
     lib().orc_sample_cone_local(width_rad, len(u), sample_dist, p_in_cone,
                                 u.ctypes.data_as(fp), r.ctypes.data_as(fp), out.ctypes.data_as(fp))
     return out
+
+
+def noise_amplitude(signal, max_val, at_signal_0, at_signal_1):
+    return float(lib().orc_noise_amplitude(signal, max_val, at_signal_0, at_signal_1))
 
 
 def cone_radius(width, sample_dist, p_in_cone, variate):

@@ -729,6 +729,21 @@ static void sv_push(sig_vec* v, double time, double strength)
     v->p[v->n].time = time; v->p[v->n].strength = strength; v->n++;
 }
 
+/* RadarCPU.cpp:497-512: amplitude of the ambient noise of one bin as a function of its signal (signal_min = 0,
+ * signal_max = the column's max_val); the law of scripts/func_deformer.py:6-21 (noise_amplitude) with the labels the C++
+ * uses: noise_at_0 scales the amplitude where the signal is 0, noise_at_1 where it is at its maximum */
+float orc_noise_amplitude(float signal, float max_val, double at_signal_0, double at_signal_1)
+{
+    float signal_min = 0;
+    float signal_max = max_val;
+    float signal_amp = signal_max - signal_min;
+    float signal_ = (float)(1.0 - (double)((signal - signal_min) / signal_amp));
+    float noise_at_0 = (float)((double)signal_amp * at_signal_0);
+    float noise_at_1 = (float)((double)signal_amp * at_signal_1);
+    float signal__ = (float)pow((double)signal_, 4.0);
+    return (float)((double)(signal__ * noise_at_0) + (1.0 - (double)signal__) * (double)noise_at_1);
+}
+
 /* counter-based uniform in [0,1) for ambient_noise==1; the reference draws
  * from std::random_device there (RadarCPU.cpp:461-482) -> unreproducible, so
  * the variate stream is DEFINED here (and identically in the product). */
@@ -991,14 +1006,8 @@ static int simulate_impl(const orc_scene* scene,
                     double p2 = orc_perlin_noise(random_begin + (double)i * scale2, (double)col * scale2, 0.0);
                     p = 0.9 * p1 + 0.1 * p2;
                 }
-                float signal_min = 0;
                 float signal_max = max_val;
-                float signal_amp = signal_max - signal_min;
-                float signal_ = (float)(1.0 - (double)((signal - signal_min) / signal_amp));
-                float noise_at_0 = (float)((double)signal_amp * cfg->ambient_noise_at_signal_0);
-                float noise_at_1 = (float)((double)signal_amp * cfg->ambient_noise_at_signal_1);
-                float signal__ = (float)pow((double)signal_, 4.0);
-                float noise_amp = (float)((double)(signal__ * noise_at_0) + (1.0 - (double)signal__) * (double)noise_at_1);
+                float noise_amp = orc_noise_amplitude(signal, max_val, cfg->ambient_noise_at_signal_0, cfg->ambient_noise_at_signal_1);
                 float noise_energy_max = (float)((double)signal_max * cfg->ambient_noise_energy_max);
                 float noise_energy_min = (float)((double)signal_max * cfg->ambient_noise_energy_min);
                 float energy_loss = (float)cfg->ambient_noise_energy_loss;

@@ -163,6 +163,7 @@ void orc_wave_move(float orig[3], const float dir[3], double* time, double veloc
  * caller (the reference draws them from std::random_device): u_angle[i] in
  * [0,1), r_variate[i] = U(0,1) for dist 0/1, N(0,1) for dist 2/3.
  * width in radians. out: [n][3]. */
+float orc_noise_amplitude(float signal, float max_val, double at_signal_0, double at_signal_1);
 float orc_cone_radius(float width, int sample_dist, float p_in_cone, float variate);
 void orc_sample_cone_local(float width, int n_samples, int sample_dist, float p_in_cone,
                            const float* u_angle, const float* r_variate, float* out_dirs);

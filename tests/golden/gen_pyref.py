@@ -102,4 +102,27 @@ json.dump({"_provenance": "scripts/radaray_beams.py:8-25,75-92 run from /root/re
            "D3_r1": [float(x) for x in g["r1"][:K]], "D4_r2": [float(x) for x in g["r2"][:K]]},
           open(os.path.join(HERE, "pyref_beams.json"), "w"), indent=1)
 print("wrote pyref_beams.json (%d samples per law)" % K)
+# Noise amplitude law: scripts/func_deformer.py:6-21 is an importable function (the module also draws a figure: Agg).  Its
+# labels are the mirror of the C++'s (its noise_at_0 belongs to signal_ = 0, i.e. to the STRONGEST signal; the C++'s
+# ambient_noise_at_signal_0 to a signal of 0); its constants are 0.01 / 0.4, the signal's minimum must be 0 to match
+# RadarCPU.cpp:499 (signal_min = 0).
+# (the module imports a third-party `perlin` package further down, :77, which this image lacks: only the part of the FILE
+# that defines the function -- its first 22 lines, up to the plotting script -- is executed, straight from /root/reference)
+_fd_path = os.path.join(REF, "func_deformer.py")
+_fd_src = open(_fd_path).read().split("\nN = 1000")[0]
+_fd_ns = {}
+exec(compile(_fd_src, _fd_path, "exec"), _fd_ns)
+
+
+class ref_fd:  # noqa: N801
+    noise_amplitude = staticmethod(_fd_ns["noise_amplitude"])
+
+
+sig = np.concatenate([[0.0], np.linspace(0.0, 3.7, 40) ** 2, [13.69]])
+json.dump({"_provenance": "scripts/func_deformer.py:6-21 noise_amplitude() imported from /root/reference; signal minimum 0, maximum 13.69; the "
+                          "script's constants: amplitude x 0.4 at signal 0, x 0.01 at the maximum",
+           "at_zero_signal": 0.4, "at_max_signal": 0.01, "signal": [float(x) for x in sig],
+           "noise_amp": [float(x) for x in ref_fd.noise_amplitude(sig)]},
+          open(os.path.join(HERE, "pyref_noise_amp.json"), "w"), indent=1)
+print("wrote pyref_noise_amp.json (%d samples)" % len(sig))
 print("wrote pyref_snell.json (%d cases), pyref_mb.json (%d cases)" % (len(cases), len(mb)))
