@@ -42,12 +42,22 @@ __host__ __device__ inline Quat q_mul(Quat a, Quat b)
     return r;
 }
 __host__ __device__ inline Quat q_conj(Quat a) { return { -a.x, -a.y, -a.z, a.w }; }
-// rmagine Quaternion * Vector = (q (v,0) q^-1).xyz
+// rmagine Quaternion * Vector = (q (v,0) q^-1).xyz: the two Hamilton products of q_mul in its term order, with the four
+// products by the zero w of (v, 0) left out -- each is +-0 for a finite q, and x + (+-0) = x: the same values (only the sign
+// of an exact zero can differ, which nothing downstream can see), 8 instructions per rotation less
 __host__ __device__ inline V3 q_rot(Quat q, V3 v)
 {
-    const Quat p = { v.x, v.y, v.z, 0.0f };
-    const Quat r = q_mul(q_mul(q, p), q_conj(q));
-    return { r.x, r.y, r.z };
+    Quat t;                                   // t = q * (v, 0)
+    t.x = q.w * v.x + q.y * v.z - q.z * v.y;
+    t.y = q.w * v.y - q.x * v.z + q.z * v.x;
+    t.z = q.w * v.z + q.x * v.y - q.y * v.x;
+    t.w = 0.0f - q.x * v.x - q.y * v.y - q.z * v.z;
+    const Quat c = q_conj(q);
+    V3 r;                                     // (t * q^-1).xyz
+    r.x = t.w * c.x + t.x * c.w + t.y * c.z - t.z * c.y;
+    r.y = t.w * c.y - t.x * c.z + t.y * c.w + t.z * c.x;
+    r.z = t.w * c.z + t.x * c.y - t.y * c.x + t.z * c.w;
+    return r;
 }
 
 // ------------------------------------------------------------ device params

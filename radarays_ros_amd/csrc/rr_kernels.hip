@@ -39,8 +39,10 @@ __device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t
         q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
     }
     q_am = q_mul(q_sm, q_as);
-    const V3 zero = { 0.0f, 0.0f, 0.0f };
-    t_am = v_add(q_rot(q_sm, zero), t_sm);
+    // Tas.t = 0: the reference forms R_sm * 0 + t_sm (rmagine T1 * T2).  Rotating the zero vector gives (+-0, +-0, +-0) for
+    // any finite quaternion and x + (+-0) = x, so t_am IS t_sm (only the sign of a zero component of t_sm could differ, which
+    // no ray can see): 59 instructions per wave less in k_trace than the two quaternion products of the literal form
+    t_am = t_sm;
 }
 
 struct Hit { float t; uint32_t tri; uint32_t face; };
@@ -87,7 +89,10 @@ __device__ inline RaySetup ray_setup(V3 o, V3 d)
     const float dx = fabsf(d.x) < eps ? copysignf(eps, d.x) : d.x;
     const float dy = fabsf(d.y) < eps ? copysignf(eps, d.y) : d.y;
     const float dz = fabsf(d.z) < eps ? copysignf(eps, d.z) : d.z;
-    R.idx = 1.0f / dx; R.idy = 1.0f / dy; R.idz = 1.0f / dz;
+    // v_rcp_f32 (1 ulp) instead of three IEEE divisions (~30 instructions): 1 / d only feeds the slab test, which merely
+    // has to be conservative -- an ulp of 1 / d moves a box plane by 6e-8 x t, the boxes are padded by 2e-5 x the scene's
+    // extent; the triangle test does not use it, so hits stay bit-exact (tests/fuzz/fuzz_trace.py)
+    R.idx = __builtin_amdgcn_rcpf(dx); R.idy = __builtin_amdgcn_rcpf(dy); R.idz = __builtin_amdgcn_rcpf(dz);
     R.oox = -o.x * R.idx; R.ooy = -o.y * R.idy; R.ooz = -o.z * R.idz;
     return R;
 }
@@ -310,7 +315,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         }
         Quat q_am; V3 t_am;
         azimuth_frame(P, seg, q_am, t_am);
-        R = ray_setup(v_add(q_rot(q_am, orig), t_am), q_rot(q_am, dir));
+        // (pass 0: every ray starts in the sensor's origin -- rotating the zero vector is +-0, see azimuth_frame)
+        R = ray_setup(FIRST ? t_am : v_add(q_rot(q_am, orig), t_am), q_rot(q_am, dir));
     }
     const bool active = j >= 0;
 
