@@ -28,6 +28,14 @@ rank r simulates its 400/N-column block of all of them in one set of launches an
 per-frame gathers fused) hands frames d*F.. to rank d -- per-GPU work per step is constant, value = N*16*K/t.
 `--strong`: one frame per batch + one all-gather (latency mode).
 
+`python bench.py --gpus N` with no launcher around it starts its own N ranks (a `torch.distributed.run` child, before this
+process touches the GPU) and exits 3 with one line when the box has fewer than N GPUs.  stdout carries the JSON line and
+nothing else (RCCL's version banner is sent to stderr).
+
+Also on the line: `single_frame_sync` (ONE synchronous rr_simulate per frame: the reference's own call shape,
+radar_simulator.cpp:197-212) and `strong_scaling_proxy` (a block of 400/N azimuth columns alone on the GPU against the
+whole frame: the bound of what sharding ONE frame over N GPUs can win; the default N > 1 mode is weak scaling).
+
 Extra objects on the JSON line:
   "roofline"     the kernel that takes the most GPU time (picked from the measured per-kernel times, normally the
                  later-pass k_trace) against the bound that really limits it: VALU instruction issue.
@@ -36,6 +44,8 @@ Extra objects on the JSON line:
                  begin/end events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64
                  VALU instruction (SIMD-32) = 1.2288 T/s.  HBM traffic (PMC) and the algorithmic byte rate are
                  secondary keys -- the tree is served by L1/L2, HBM runs at a few percent of its peak.
+                 `useful_issue_frac`: the share of the issued lane-work that advanced a ray (statistics build).  The
+                 counters file carries a hash of the kernel sources: when it does not match, `frac` is withheld.
   "cpu_baseline" (N = 1, rank 0) the CPU oracle = line-faithful port of RadarCPU::simulate, OpenMP over azimuths
                  like RadarCPU.cpp:155, timed on a bounded sample of the same workload.
 """
