@@ -418,6 +418,9 @@ void rr_free_mesh(rr_mesh* m);
  *                         vertical weight 0.5 / 1.0), trace one sample of radar-like rays through each, keep the tree with
  *                         the fewest traversal steps; 0: the default tree only (images are the same whichever tree)
  * RR_MULTI_LOOPBACK (0)   1: rr_create_multi accepts one device several times (tests, see above)
+ * RR_MULTI_SELF_RCCL (0)  1 with ONE device: its block travels to itself through the real RCCL calls (one-rank communicator, a
+ *                         group of ncclSend / ncclRecv to self; 2: one pair per frame, the ragged plan) instead of the
+ *                         single-device route (tests on one-GPU boxes)
  * RR_MULTI_SLOTS (4)      batches rr_multi keeps in flight (streams + buffer sets per device, 1..8) */
 
 #ifdef __cplusplus

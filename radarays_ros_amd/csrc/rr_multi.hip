@@ -95,6 +95,8 @@ struct rr_multi {
     rr_config cfg;
     bool have_cfg = false;
     bool loopback = false;                // see rr_create_multi
+    bool self_rccl = false;               // RR_MULTI_SELF_RCCL=1 with ONE device: its block travels to itself through RCCL (test switch)
+    bool self_rccl_frames = false;        // ... =2: frame by frame (the ragged plan's many pieces in one group)
     std::string err;
 };
 
@@ -141,7 +143,8 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
     // One device: a batch owns no buffers here (its images wait on the ctx's frame lane until the lane's next batch carries
     // them out), so the records outnumber the streams two to one -- a call then waits for the batch EIGHT back, not for
     // the one whose deferred images its own launches are about to carry (that wait would force the plain copy every time)
-    m->slots.resize((size_t)(n_devices == 1 ? 2 * n_slots : n_slots));
+    const bool self_rccl_early = n_devices == 1 && !loopback && getenv("RR_MULTI_SELF_RCCL") && atoi(getenv("RR_MULTI_SELF_RCCL")) != 0;
+    m->slots.resize((size_t)((n_devices == 1 && !self_rccl_early) ? 2 * n_slots : n_slots));
     for (size_t si = 0; si < m->slots.size(); si++) {
         MultiSlot& S = m->slots[si];
         S.block.resize((size_t)n_devices);
@@ -158,7 +161,13 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
         if (!ok) { g_multi_create_error = "rr_create_multi: stream / event creation failed"; rr_destroy_multi(m); return nullptr; }
         for (int i = 0; i < n_devices; i++) S.h_bits[i] = 0;
     }
-    if (n_devices > 1 && !loopback) {
+    // RR_MULTI_SELF_RCCL=1 (test switch for one-GPU boxes, the complement of the loopback): ONE device whose block goes
+    // through the REAL RCCL calls -- ncclCommInitAll with one rank, one group of ncclSend / ncclRecv to itself on the slot's
+    // stream -- instead of the single-device route: what the loopback leaves out (library loading, symbols, datatype,
+    // group semantics, stream ordering of the collective against render and transpose) runs here
+    m->self_rccl = n_devices == 1 && !loopback && getenv("RR_MULTI_SELF_RCCL") && atoi(getenv("RR_MULTI_SELF_RCCL")) != 0;
+    m->self_rccl_frames = m->self_rccl && atoi(getenv("RR_MULTI_SELF_RCCL")) == 2;
+    if ((n_devices > 1 && !loopback) || m->self_rccl) {
         // the communicator is owned here: one rank per device of this process
         if (!g_rccl.load(g_multi_create_error)) { rr_destroy_multi(m); return nullptr; }
         m->comms.resize((size_t)n_devices, nullptr);
@@ -307,7 +316,7 @@ int wait_slot(rr_multi* m, MultiSlot& S)
     if (!S.pending) return 0;
     const int n = (int)m->ctx.size();
     hipError_t e = hipSetDevice(m->devices[0]);
-    if (e == hipSuccess && n == 1) {
+    if (e == hipSuccess && n == 1 && !m->self_rccl) {
         // the image may still sit on its frame lane (rr_simulate_batch_host_async defers the copy): deliver it
         if (rr_wait_host(m->ctx[0], S.dst)) return fail_drained(m, -100, std::string("device ") + std::to_string(m->devices[0]) + ": " + rr_last_error(m->ctx[0]));
     }
@@ -353,7 +362,7 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     m->next_slot = (m->next_slot + 1) % m->slots.size();
     { const int rc = wait_slot(m, S); if (rc) return rc; }        // the batch that used this slot's buffers last
     const auto dev_msg = [&](int i) { return std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rr_last_error(m->ctx[(size_t)i]); };
-    if (n == 1) {
+    if (n == 1 && !m->self_rccl) {
         // one device: no collective; the images take the ctx's own host delivery (deferred, trickled out by the next
         // batch's trace launches: within 1 % of leaving them in HBM)
         RRM_HIP(m, hipSetDevice(m->devices[0]));
@@ -371,6 +380,7 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     std::vector<int> b((size_t)n), e((size_t)n);
     bool equal = true;
     for (int i = 0; i < n; i++) { rr_partition(A, n, i, &b[(size_t)i], &e[(size_t)i]); equal = equal && (e[(size_t)i] - b[(size_t)i]) == (e[0] - b[0]); }
+    if (m->self_rccl_frames) equal = false;      // (test switch: one send / recv pair per frame, as ragged blocks travel)
     // 1. every device renders its block of all frames (one set of launches each, all devices concurrently)
     for (int i = 0; i < n; i++) {
         const size_t nl = (size_t)(e[(size_t)i] - b[(size_t)i]);
@@ -409,7 +419,7 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     }
     d_cols = S.gathered.p;
     for (const Piece& p : pieces)          // the root's own pieces (and, in loopback, everybody's): plain copies on the root's stream
-        if (p.dev == 0 || m->loopback) {
+        if ((p.dev == 0 && !m->self_rccl) || m->loopback) {
             if (p.dev != 0) RRM_TRY_HIP(hipStreamWaitEvent(S.streams[0], S.ev_block[(size_t)p.dev], 0));
             RRM_TRY_HIP(hipMemcpyAsync(S.gathered.p + p.ro, S.block[(size_t)p.dev].p + p.so, p.bytes, hipMemcpyDeviceToDevice, S.streams[0]));
         }
@@ -417,7 +427,7 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
         RRM_TRY_NCCL(g_rccl.GroupStart());
         ncclResult_t gr = 0; hipError_t ge = hipSuccess;          // a failure inside the group still has to close the group
         for (const Piece& p : pieces) {
-            if (p.dev == 0 || gr != 0 || ge != hipSuccess) continue;
+            if ((p.dev == 0 && !m->self_rccl) || gr != 0 || ge != hipSuccess) continue;
             // (one thread drives every device: the current device follows the communicator a call is made on)
             ge = hipSetDevice(m->devices[(size_t)p.dev]);
             if (ge == hipSuccess) gr = g_rccl.Send(S.block[(size_t)p.dev].p + p.so, p.bytes, kNcclUint8, 0, m->comms[(size_t)p.dev], S.streams[(size_t)p.dev]);

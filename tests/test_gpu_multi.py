@@ -138,6 +138,36 @@ def test_multi_async_error_is_reported_once_and_drains(native_lib, small, monkey
     m.close()
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_multi_real_rccl_calls_on_one_gpu(native_lib, small, monkeypatch, mode):
+    """RR_MULTI_SELF_RCCL: what the loopback leaves out, on a one-GPU box -- librccl loaded at run time, ncclCommInitAll
+    (one rank), ONE group of ncclSend / ncclRecv per call on the slot's stream (mode 1: the block as one piece, the equal
+    plan; mode 2: one pair per frame, the ragged plan), ordered between the render and the transpose -- the device sends
+    its block to itself.  Synchronous and pipelined calls, byte-equal to rr_simulate."""
+    s, cfg, mats, beams, noise, poses = small
+    monkeypatch.setenv("RR_MULTI_SELF_RCCL", mode)
+    m = native_lib.MultiContext([0])
+    monkeypatch.delenv("RR_MULTI_SELF_RCCL")
+    _setup(m, s, cfg, mats, beams, noise)
+    batches = [poses[0:4], poses[4:5], poses[5:8]]
+    refs = _reference_frames(native_lib, small, batches)
+    for b, batch in enumerate(batches):
+        assert np.array_equal(m.simulate_batch(batch), refs[b]), (mode, b)
+    ring = [native_lib.HostImages((4, cfg.n_cells, 400)) for _ in range(3)]
+    for rep in range(4):                      # 12 pipelined batches over 4 slots
+        for b, batch in enumerate(batches):
+            m.wait(ring[b].ptr)
+            if rep:
+                assert np.array_equal(ring[b].array[:len(batch)], refs[b]), (mode, rep, b)
+            m.simulate_batch_async(batch, ring[b].ptr)
+    m.wait(None)
+    for b, batch in enumerate(batches):
+        assert np.array_equal(ring[b].array[:len(batch)], refs[b]), (mode, b)
+    for h in ring:
+        h.close()
+    m.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # two or more GPUs: the real RCCL calls
 # ---------------------------------------------------------------------------------------------------------------
