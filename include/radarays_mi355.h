@@ -421,6 +421,9 @@ void rr_free_mesh(rr_mesh* m);
  * RR_MULTI_SELF_RCCL (0)  1 with ONE device: its block travels to itself through the real RCCL calls (one-rank communicator, a
  *                         group of ncclSend / ncclRecv to self; 2: one pair per frame, the ragged plan) instead of the
  *                         single-device route (tests on one-GPU boxes)
+ * RR_MULTI_THREADS (0)    1: rr_multi with several devices starts one enqueue thread per device, which issues that device's
+ *                         launches of a call while the others issue theirs (off by default: on one physical device, the
+ *                         only case measurable on a one-GPU box, the runtime serialises the threads and nothing is gained)
  * RR_MULTI_SLOTS (4)      batches rr_multi keeps in flight (streams + buffer sets per device, 1..8) */
 
 #ifdef __cplusplus

@@ -22,6 +22,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -86,7 +91,22 @@ struct MultiSlot {
     bool owns_streams = true;             // one device: twice as many records as streams (see rr_create_multi)
 };
 
+// One enqueue thread per device: a call's launches for device i (a dozen kernels, an event, a copy: 60-100 us of host time)
+// are issued by worker i while the others issue theirs -- from ONE thread the host side of a call grows with the number
+// of devices (measured in loopback, config 2, 8 entries: 450 us per 8-frame call = a cap of 17.6k images/s whatever the GPUs
+// do).  A context is used by one thread at a time (the header's rule): worker i is the only one that touches context i
+// while a call renders; the caller's thread takes over (collective, root) only after every worker has reported back.
+struct MultiWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, quit = false;
+    int rc = 0;
+};
+
 struct rr_multi {
+    std::vector<std::unique_ptr<MultiWorker>> workers;     // empty: the caller's thread issues everything (the default; RR_MULTI_THREADS=1 starts them)
     std::vector<int> devices;
     std::vector<rr_ctx*> ctx;
     std::vector<ncclComm_t> comms;
@@ -167,6 +187,29 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
     // group semantics, stream ordering of the collective against render and transpose) runs here
     m->self_rccl = n_devices == 1 && !loopback && getenv("RR_MULTI_SELF_RCCL") && atoi(getenv("RR_MULTI_SELF_RCCL")) != 0;
     m->self_rccl_frames = m->self_rccl && atoi(getenv("RR_MULTI_SELF_RCCL")) == 2;
+    if (n_devices > 1 && getenv("RR_MULTI_THREADS") && atoi(getenv("RR_MULTI_THREADS")) != 0) {
+        for (int i = 0; i < n_devices; i++) {
+            m->workers.emplace_back(new MultiWorker());
+            MultiWorker* w = m->workers.back().get();
+            const int dev = devices[i];
+            try {
+                w->th = std::thread([w, dev] {
+                    (void)hipSetDevice(dev);
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    for (;;) {
+                        w->cv.wait(lk, [w] { return w->has_job || w->quit; });
+                        if (w->quit) return;
+                        w->has_job = false;
+                        lk.unlock();
+                        const int rc = w->job();
+                        lk.lock();
+                        w->rc = rc; w->done = true;
+                        w->cv.notify_all();
+                    }
+                });
+            } catch (...) { m->workers.clear(); break; }       // no thread to be had: the caller's thread does the work
+        }
+    }
     if ((n_devices > 1 && !loopback) || m->self_rccl) {
         // the communicator is owned here: one rank per device of this process
         if (!g_rccl.load(g_multi_create_error)) { rr_destroy_multi(m); return nullptr; }
@@ -180,6 +223,12 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
 void rr_destroy_multi(rr_multi* m)
 {
     if (!m) return;
+    for (auto& w : m->workers) {
+        { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
+    m->workers.clear();
     for (size_t i = 0; i < m->ctx.size(); i++) { (void)hipSetDevice(m->devices[i]); (void)hipDeviceSynchronize(); }
     for (size_t i = 0; i < m->comms.size(); i++) if (m->comms[i]) g_rccl.CommDestroy(m->comms[i]);
     for (MultiSlot& S : m->slots) {
@@ -382,19 +431,42 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     for (int i = 0; i < n; i++) { rr_partition(A, n, i, &b[(size_t)i], &e[(size_t)i]); equal = equal && (e[(size_t)i] - b[(size_t)i]) == (e[0] - b[0]); }
     if (m->self_rccl_frames) equal = false;      // (test switch: one send / recv pair per frame, as ragged blocks travel)
     // 1. every device renders its block of all frames (one set of launches each, all devices concurrently)
-    for (int i = 0; i < n; i++) {
+    //    -- each device's launches from its own enqueue thread where there are several devices (MultiWorker)
+    std::vector<std::string> hip_err((size_t)n);
+    auto render = [&](int i) -> int {          // rc of the context, or -100 with hip_err[i] set
         const size_t nl = (size_t)(e[(size_t)i] - b[(size_t)i]);
-        RRM_TRY_HIP(hipSetDevice(m->devices[(size_t)i]));
-        RRM_TRY_HIP(S.block[(size_t)i].ensure(std::max<size_t>(1, (size_t)n_frames * nl * C)));
+        hipError_t he = hipSetDevice(m->devices[(size_t)i]);
+        if (he == hipSuccess) he = S.block[(size_t)i].ensure(std::max<size_t>(1, (size_t)n_frames * nl * C));
         S.h_bits[i] = 0;
-        if (nl > 0) {
+        int rc = 0;
+        if (he == hipSuccess && nl > 0) {
             rr_ctx* c = m->ctx[(size_t)i];
-            int rc = rr_simulate_batch_columns_device(c, poses, n_frames, b[(size_t)i], e[(size_t)i], S.block[(size_t)i].p, S.streams[(size_t)i]);
+            rc = rr_simulate_batch_columns_device(c, poses, n_frames, b[(size_t)i], e[(size_t)i], S.block[(size_t)i].p, S.streams[(size_t)i]);
             if (!rc) rc = rr_peek_error_bits_async(c, &S.h_bits[i], S.streams[(size_t)i]);
-            if (rc) return fail_drained(m, rc, dev_msg(i));
+            if (rc) return rc;
         }
-        RRM_TRY_HIP(hipEventRecord(S.ev_block[(size_t)i], S.streams[(size_t)i]));
+        if (he == hipSuccess) he = hipEventRecord(S.ev_block[(size_t)i], S.streams[(size_t)i]);
+        if (he != hipSuccess) { hip_err[(size_t)i] = hipGetErrorString(he); return -100; }
+        return 0;
+    };
+    std::vector<int> rcs((size_t)n, 0);
+    if (!m->workers.empty()) {
+        for (int i = 0; i < n; i++) {
+            MultiWorker* w = m->workers[(size_t)i].get();
+            { std::lock_guard<std::mutex> lk(w->mu); w->job = [&render, i] { return render(i); }; w->done = false; w->has_job = true; }
+            w->cv.notify_all();
+        }
+        for (int i = 0; i < n; i++) {
+            MultiWorker* w = m->workers[(size_t)i].get();
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [w] { return w->done; });
+            rcs[(size_t)i] = w->rc;
+        }
+    } else {
+        for (int i = 0; i < n && (i == 0 || rcs[(size_t)i - 1] == 0); i++) rcs[(size_t)i] = render(i);
     }
+    for (int i = 0; i < n; i++)
+        if (rcs[(size_t)i]) return fail_drained(m, rcs[(size_t)i], hip_err[(size_t)i].empty() ? dev_msg(i) : std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + hip_err[(size_t)i]);
     // 2. ONE collective: a GATHER to the root (device 0), nobody else receives anything.  RCCL has no plain gather in
     //    every version, so it is one group of send / recv pairs along rr_multi_plan: equal blocks travel as one piece
     //    per device into the layout [device][frame][n_loc][n_cells], ragged ones frame by frame into

@@ -66,15 +66,18 @@ def _reference_frames(native_lib, small, poses_batches):
     return out
 
 
-@pytest.mark.parametrize("n_dev", [1, 2, 3, 8])
-def test_multi_async_batches_in_flight(native_lib, small, monkeypatch, n_dev):
+@pytest.mark.parametrize("n_dev,threads", [(1, 0), (2, 0), (3, 0), (8, 0), (3, 1), (8, 1)])
+def test_multi_async_batches_in_flight(native_lib, small, monkeypatch, n_dev, threads):
     """rr_multi_simulate_batch_async: 7 batches of different sizes issued back to back over a ring of 5 host buffers
     (more batches than slots: a call that finds its slot busy waits for the older batch itself), waited for in a
     scrambled order -- every image equals rr_simulate's.  n_dev = 1: the single-device route (deferred host copy);
-    n_dev > 1: the n-device path in loopback (equal blocks 2 / 8, ragged 3)."""
+    n_dev > 1: the n-device path in loopback (equal blocks 2 / 8, ragged 3); threads = 1: RR_MULTI_THREADS, one enqueue
+    thread per device entry issues that entry's launches."""
     s, cfg, mats, beams, noise, poses = small
     if n_dev > 1:
         monkeypatch.setenv("RR_MULTI_LOOPBACK", "1")
+    if threads:
+        monkeypatch.setenv("RR_MULTI_THREADS", "1")
     m = native_lib.MultiContext([0] * n_dev)
     _setup(m, s, cfg, mats, beams, noise)
     sizes = [3, 1, 4, 2, 4, 1, 3]
@@ -109,14 +112,16 @@ def test_multi_async_batches_in_flight(native_lib, small, monkeypatch, n_dev):
     m.close()
 
 
-@pytest.mark.parametrize("n_dev", [1, 3])
-def test_multi_async_error_is_reported_once_and_drains(native_lib, small, monkeypatch, n_dev):
+@pytest.mark.parametrize("n_dev,threads", [(1, 0), (3, 0), (3, 1)])
+def test_multi_async_error_is_reported_once_and_drains(native_lib, small, monkeypatch, n_dev, threads):
     """A batch that overflows its wave queue inside the pipeline: rr_multi_wait returns -7 for it; after the error return
     nothing is in flight (a late D2H copy must not hit a freed buffer, sticky bits must not fail the next
     call), and the next, healthy batch renders the right bytes."""
     s, cfg, mats, beams, noise, poses = small
     if n_dev > 1:
         monkeypatch.setenv("RR_MULTI_LOOPBACK", "1")
+    if threads:
+        monkeypatch.setenv("RR_MULTI_THREADS", "1")
     m = native_lib.MultiContext([0] * n_dev)
     _setup(m, s, cfg, mats, beams, noise)
     good = [poses[0], poses[1]]

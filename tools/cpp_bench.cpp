@@ -110,8 +110,11 @@ int main(int argc, char** argv)
         const double t_ctx = secs(a, clk::now());
         std::printf("rr_simulate_batch_host_async, %d poses per call, 4 streams: %.0f images/s host-resident\n", batch, steps * batch / t_ctx);
         rr_destroy(c);
-        const int dev0 = 0;
-        rr_multi* m = rr_create_multi(&dev0, 1);
+        // CPP_BENCH_NDEV=n with RR_MULTI_LOOPBACK=1: device 0 listed n times -- the n-device orchestration (n contexts, n x the
+        // launches per call from ONE host thread, plan-driven copies in place of the collective) on one GPU: what the host side costs
+        const int ndev = getenv("CPP_BENCH_NDEV") ? std::max(1, atoi(getenv("CPP_BENCH_NDEV"))) : 1;
+        std::vector<int> devs((size_t)ndev, 0);
+        rr_multi* m = rr_create_multi(devs.data(), ndev);
         if (!m) { std::fprintf(stderr, "%s\n", rr_multi_last_error(nullptr)); return 6; }
 #define MK(x) do { if ((x) != 0) { std::fprintf(stderr, "%s: %s\n", #x, rr_multi_last_error(m)); return 1; } } while (0)
         MK(rr_multi_set_mesh(m, verts.data(), verts.size() / 3, faces.data(), faces.size() / 3, fobj.data()));
@@ -119,11 +122,15 @@ int main(int argc, char** argv)
         MK(rr_multi_set_config(m, &cfg));
         MK(rr_multi_set_beam_samples(m, beams.data(), beams.size() / 3));
         MK(rr_multi_set_noise_offsets(m, rnd.data(), rnd.size()));
+        double t_enq = 0.0;
         auto run_multi = [&](int n) -> int {
+            t_enq = 0.0;
             for (int k = 0; k < n; k++) {
                 uint8_t* h = host[k % ring];
                 if (rr_multi_wait(m, h)) return 1;
+                auto q0 = clk::now();
                 if (rr_multi_simulate_batch_async(m, &poses[7 * (k % (32 - batch + 1))], batch, h)) return 1;
+                t_enq += secs(q0, clk::now());
             }
             return rr_multi_wait(m, nullptr);
         };
@@ -131,8 +138,9 @@ int main(int argc, char** argv)
         a = clk::now();
         MK(run_multi(steps));
         const double t_m = secs(a, clk::now());
-        std::printf("rr_multi_simulate_batch_async {0}, %d poses per call: %.0f images/s host-resident = %.1f %% of the ctx route\n", batch,
-                    steps * batch / t_m, 100.0 * t_ctx / t_m);
+        std::printf("rr_multi_simulate_batch_async over %d device entr%s, %d poses per call: %.0f images/s host-resident = %.1f %% of the ctx route; "
+                    "host time per call %.1f us (%.1f us per frame)\n", ndev, ndev == 1 ? "y" : "ies", batch,
+                    steps * batch / t_m, 100.0 * t_ctx / t_m, 1e6 * t_enq / steps, 1e6 * t_enq / steps / batch);
         rr_destroy_multi(m);
         for (auto h : host) rr_host_free(h);
         return 0;
