@@ -388,16 +388,20 @@ int rr_cone_dirs(float width_rad, int sample_dist, float p_in_cone, const float*
 int rr_sample_cone_local(uint32_t seed, float width_rad, size_t n, int sample_dist, float p_in_cone, float* out_dirs);
 
 /* The map file, as rm::import_embree_map(map_file) reads it for the node (src/radar_simulator.cpp:149): PLY (ascii,
- * binary little / big endian; MulRan maps, launch/mulran_sim.launch:7) and Wavefront OBJ (objects `o` / `g` become
- * object ids, the index into object_materials) into the flat arrays rr_set_mesh takes; polygons are fan-triangulated.
- * The arrays are malloc'ed: give them back with rr_free_mesh.  <0 + text in err on failure.  (COLLADA: meshio.py.) */
+ * binary little / big endian; MulRan maps, launch/mulran_sim.launch:7), Wavefront OBJ (objects `o` / `g` become
+ * object ids, the index into object_materials) and COLLADA .dae (the reference's default map, launch/mro_husky.launch:4;
+ * csrc/rr_collada.cpp: one object per instantiated geometry / primitive group, depth-first in scene order, node
+ * transforms and <unit meter> applied, the up axis left as modelled) into the flat arrays rr_set_mesh takes; polygons
+ * are fan-triangulated.  The arrays are malloc'ed: give them back with rr_free_mesh.  <0 + text in err on failure. */
 typedef struct rr_mesh {
     float* verts;               /* [n_verts][3] */
     size_t n_verts;
     uint32_t* faces;            /* [n_faces][3] */
     size_t n_faces;
     uint32_t* face_object_id;   /* [n_faces] */
-    size_t n_objects;           /* OBJ: number of o / g groups (>= 1) */
+    size_t n_objects;           /* OBJ: number of o / g groups, DAE: instantiated primitive groups (>= 1) */
+    char** object_names;        /* [n_objects] NUL-terminated names (OBJ group / DAE geometry names), or NULL (PLY):
+                                   what to match a scene's material table against */
 } rr_mesh;
 int rr_load_mesh_file(const char* path, rr_mesh* out, char* err, size_t err_len);
 void rr_free_mesh(rr_mesh* m);

@@ -11,7 +11,7 @@
 //   * the map loader: what rm::import_embree_map(map_file) does for the node (src/radar_simulator.cpp:149): PLY
 //     (ascii / binary, either byte order; MulRan maps are .ply, launch/mulran_sim.launch:7) and Wavefront OBJ
 //     (objects `o` / `g` -> object ids) into the flat arrays rr_set_mesh takes; polygons are fan-triangulated.
-//     Same results as radarays_ros_amd/meshio.py (tests/test_host_side.py).  COLLADA is read by meshio.py only.
+//     Same results as radarays_ros_amd/meshio.py (tests/test_host_side.py).  COLLADA: rr_collada.cpp.
 //
 // No GPU, no HIP call in this file.
 #include "../../include/radarays_mi355.h"
@@ -27,6 +27,11 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+namespace rr_collada {
+bool load_dae(const std::string& path, std::vector<float>& verts, std::vector<uint32_t>& faces, std::vector<uint32_t>& obj,
+              std::vector<std::string>& names, std::string& err);
+}
 
 namespace {
 
@@ -220,11 +225,11 @@ bool load_ply(const std::string& path, std::vector<float>& verts, std::vector<ui
 
 // ---- OBJ ----------------------------------------------------------------------------------------------------
 bool load_obj(const std::string& path, std::vector<float>& verts, std::vector<uint32_t>& faces, std::vector<uint32_t>& obj,
-              size_t& n_objects, std::string& err)
+              std::vector<std::string>& names, std::string& err)
 {
     std::ifstream f(path);
     if (!f) { err = path + ": cannot open"; return false; }
-    std::string line; long long cur = -1; n_objects = 0;
+    std::string line; long long cur = -1;
     std::vector<long long> idx;
     while (std::getline(f, line)) {
         std::istringstream ss(line); std::string t; ss >> t;
@@ -233,7 +238,10 @@ bool load_obj(const std::string& path, std::vector<float>& verts, std::vector<ui
             double x, y, z;
             if (ss >> x >> y >> z) { verts.push_back((float)x); verts.push_back((float)y); verts.push_back((float)z); }
         } else if (t == "o" || t == "g") {
-            cur = (long long)n_objects++;
+            std::string name, w;
+            while (ss >> w) { if (!name.empty()) name += ' '; name += w; }
+            cur = (long long)names.size();
+            names.push_back(name);
         } else if (t == "f") {
             idx.clear();
             std::string tok;
@@ -296,13 +304,14 @@ int rr_load_mesh_file(const char* path, rr_mesh* out, char* err, size_t err_len)
     const std::string p(path);
     std::string ext = p.size() >= 4 ? p.substr(p.size() - 4) : "";
     for (char& ch : ext) ch = (char)std::tolower((unsigned char)ch);
-    std::vector<float> verts; std::vector<uint32_t> faces, obj; size_t n_obj = 0; std::string e;
+    std::vector<float> verts; std::vector<uint32_t> faces, obj; std::vector<std::string> names; std::string e;
     try {
         if (ext == ".ply") { if (!load_ply(p, verts, faces, e)) { set_err(err, err_len, e); return -4; } obj.assign(faces.size() / 3, 0u); }
-        else if (ext == ".obj") { if (!load_obj(p, verts, faces, obj, n_obj, e)) { set_err(err, err_len, e); return -4; } }
-        else { set_err(err, err_len, p + ": unsupported mesh format (PLY and OBJ are read here; COLLADA by radarays_ros_amd/meshio.py)"); return -4; }
+        else if (ext == ".obj") { if (!load_obj(p, verts, faces, obj, names, e)) { set_err(err, err_len, e); return -4; } }
+        else if (ext == ".dae") { if (!rr_collada::load_dae(p, verts, faces, obj, names, e)) { set_err(err, err_len, e); return -4; } }
+        else { set_err(err, err_len, p + ": unsupported mesh format (PLY, OBJ and COLLADA are read)"); return -4; }
     } catch (const std::exception& ex) { set_err(err, err_len, p + ": " + ex.what()); return -4; }
-    const size_t nv = verts.size() / 3, nf = faces.size() / 3;
+    const size_t nv = verts.size() / 3, nf = faces.size() / 3, n_obj = names.size();
     for (uint32_t i : faces) if ((size_t)i >= nv) { set_err(err, err_len, p + ": face index out of range"); return -4; }
     out->verts = (float*)std::malloc(std::max<size_t>(1, verts.size()) * sizeof(float));
     out->faces = (uint32_t*)std::malloc(std::max<size_t>(1, faces.size()) * sizeof(uint32_t));
@@ -312,6 +321,16 @@ int rr_load_mesh_file(const char* path, rr_mesh* out, char* err, size_t err_len)
     if (!faces.empty()) std::memcpy(out->faces, faces.data(), faces.size() * sizeof(uint32_t));
     if (nf) std::memcpy(out->face_object_id, obj.data(), nf * sizeof(uint32_t));
     out->n_verts = nv; out->n_faces = nf; out->n_objects = std::max<size_t>(1, n_obj);
+    if (n_obj) {
+        out->object_names = (char**)std::calloc(n_obj, sizeof(char*));
+        bool ok = out->object_names != nullptr;
+        for (size_t k = 0; ok && k < n_obj; k++) {
+            out->object_names[k] = (char*)std::malloc(names[k].size() + 1);
+            if (!out->object_names[k]) { ok = false; break; }
+            std::memcpy(out->object_names[k], names[k].c_str(), names[k].size() + 1);
+        }
+        if (!ok) { rr_free_mesh(out); set_err(err, err_len, "rr_load_mesh_file: out of memory"); return -4; }
+    }
     return 0;
 }
 
@@ -319,6 +338,7 @@ void rr_free_mesh(rr_mesh* m)
 {
     if (!m) return;
     std::free(m->verts); std::free(m->faces); std::free(m->face_object_id);
+    if (m->object_names) { for (size_t k = 0; k < m->n_objects; k++) std::free(m->object_names[k]); std::free(m->object_names); }
     std::memset(m, 0, sizeof(*m));
 }
 

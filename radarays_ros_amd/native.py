@@ -64,7 +64,7 @@ class RRParamSet(C.Structure):
 
 class RRMesh(C.Structure):
     _fields_ = [("verts", C.POINTER(C.c_float)), ("n_verts", C.c_size_t), ("faces", C.POINTER(C.c_uint32)), ("n_faces", C.c_size_t),
-                ("face_object_id", C.POINTER(C.c_uint32)), ("n_objects", C.c_size_t)]
+                ("face_object_id", C.POINTER(C.c_uint32)), ("n_objects", C.c_size_t), ("object_names", C.POINTER(C.c_char_p))]
 
 
 class RRStats(C.Structure):
@@ -514,7 +514,7 @@ def sample_cone_local(seed, width_rad, n, sample_dist=2, p_in_cone=0.8):
 
 
 def load_mesh_file(path):
-    """rr_load_mesh_file (host only): PLY / OBJ -> {"verts", "faces", "face_object_id", "n_objects"}."""
+    """rr_load_mesh_file (host only): PLY / OBJ / DAE -> {"verts", "faces", "face_object_id", "n_objects", "object_names"}."""
     m = RRMesh()
     err = C.create_string_buffer(512)
     rc = lib().rr_load_mesh_file(str(path).encode(), C.byref(m), err, len(err))
@@ -524,7 +524,8 @@ def load_mesh_file(path):
         out = {"verts": np.ctypeslib.as_array(m.verts, (m.n_verts, 3)).copy() if m.n_verts else np.zeros((0, 3), np.float32),
                "faces": np.ctypeslib.as_array(m.faces, (m.n_faces, 3)).copy() if m.n_faces else np.zeros((0, 3), np.uint32),
                "face_object_id": np.ctypeslib.as_array(m.face_object_id, (m.n_faces,)).copy() if m.n_faces else np.zeros(0, np.uint32),
-               "n_objects": int(m.n_objects)}
+               "n_objects": int(m.n_objects),
+               "object_names": [m.object_names[k].decode(errors="replace") for k in range(m.n_objects)] if m.object_names else []}
     finally:
         lib().rr_free_mesh(C.byref(m))
     return out

@@ -1,7 +1,7 @@
-// rr_host.cpp (the host-only pieces of the C ABI: beam sampler, PLY / OBJ map loader) under AddressSanitizer + UBSan:
+// rr_host.cpp + rr_collada.cpp (the host-only pieces of the C ABI: beam sampler, PLY / OBJ / COLLADA map loader) under AddressSanitizer + UBSan:
 // well-formed files, then thousands of damaged ones (truncated, bytes flipped, counts inflated) -- the loader parses files
 // from disk, it must fail with an error code, never with a crash or an out-of-bounds access.
-//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -I include tests/cpp/host_side_check.cpp radarays_ros_amd/csrc/rr_host.cpp -o /tmp/hsc && /tmp/hsc /tmp
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -I include tests/cpp/host_side_check.cpp radarays_ros_amd/csrc/rr_host.cpp radarays_ros_amd/csrc/rr_collada.cpp -o /tmp/hsc && /tmp/hsc /tmp
 #include <radarays_mi355.h>
 
 #include <cmath>
@@ -42,8 +42,27 @@ int main(int argc, char** argv)
     { const double v[9] = { 0, 0, 0, 1, 0, 0, 0, 1, 0 }; ply_bin.append((const char*)v, sizeof(v)); const unsigned char c = 3; ply_bin.push_back((char)c);
       const uint32_t idx[3] = { 0, 1, 2 }; ply_bin.append((const char*)idx, sizeof(idx)); }
     const std::string obj = "# c\no a\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\ng b\nf -4//1 -3//1 -2//1\nvn 0 0 1\n";
-    struct Case { const char* name; std::string ext, bytes; size_t nv, nf; } good[3] = {
-        { "ply ascii", ".ply", ply_ascii, 4, 3 }, { "ply binary", ".ply", ply_bin, 3, 1 }, { "obj", ".obj", obj, 4, 3 } };
+    // COLLADA: two geometries (polylist with two inputs per corner, triangles), nested nodes, a library node instantiated
+    // by the scene, every transform element, a comment, a CDATA array
+    const std::string dae =
+        "<?xml version=\"1.0\"?>\n<!-- c --><COLLADA xmlns=\"http://www.collada.org/2005/11/COLLADASchema\" version=\"1.4.1\">"
+        "<asset><unit name=\"cm\" meter=\"0.5\"/><up_axis>Z_UP</up_axis></asset><library_geometries>"
+        "<geometry id=\"W\" name=\"Wall\"><mesh><source id=\"Wp\"><float_array id=\"Wa\" count=\"12\">0 0 0 1 0 0 1 1 0 0 1 0</float_array>"
+        "<technique_common><accessor source=\"#Wa\" count=\"4\" stride=\"3\"/></technique_common></source>"
+        "<vertices id=\"Wv\"><input semantic=\"POSITION\" source=\"#Wp\"/></vertices>"
+        "<polylist count=\"1\" material=\"m0\"><input semantic=\"VERTEX\" source=\"#Wv\" offset=\"0\"/><input semantic=\"NORMAL\" source=\"#n\" offset=\"1\"/>"
+        "<vcount>4</vcount><p>0 0 1 0 2 0 3 0</p></polylist><tristrips count=\"1\" material=\"m1\"><input semantic=\"VERTEX\" source=\"#Wv\" offset=\"0\"/><p>0 1 3 2</p></tristrips></mesh></geometry>"
+        "<geometry id=\"D\"><mesh><source id=\"Dp\"><float_array id=\"Da\" count=\"9\"><![CDATA[0 0 0 2 0 0 0 2 0]]></float_array>"
+        "<technique_common><accessor source=\"#Da\" count=\"3\" stride=\"3\"/></technique_common></source>"
+        "<vertices id=\"Dv\"><input semantic=\"POSITION\" source=\"#Dp\"/></vertices>"
+        "<triangles count=\"1\"><input semantic=\"VERTEX\" source=\"#Dv\" offset=\"0\"/><p>0 1 2</p></triangles></mesh></geometry></library_geometries>"
+        "<library_nodes><node id=\"L\"><scale>2 2 2</scale><instance_geometry url=\"#D\"/></node></library_nodes>"
+        "<library_visual_scenes><visual_scene id=\"S\"><node id=\"a\"><translate>10 0 0</translate><rotate>0 0 1 90</rotate><instance_geometry url=\"#D\"/></node>"
+        "<node id=\"b\"><matrix>1 0 0 0 0 1 0 5 0 0 1 0 0 0 0 1</matrix><instance_geometry url=\"#W\"/><instance_node url=\"#L\"/>"
+        "<node id=\"c\"><instance_geometry url=\"#D\"/></node></node></visual_scene></library_visual_scenes>"
+        "<scene><instance_visual_scene url=\"#S\"/></scene></COLLADA>\n";
+    struct Case { const char* name; std::string ext, bytes; size_t nv, nf; } good[4] = {
+        { "ply ascii", ".ply", ply_ascii, 4, 3 }, { "ply binary", ".ply", ply_bin, 3, 1 }, { "obj", ".obj", obj, 4, 3 }, { "dae", ".dae", dae, 21, 7 } };
     for (const Case& c : good) {
         const std::string p = dir + "/hsc_good" + c.ext;
         put(p, c.bytes);
@@ -56,8 +75,9 @@ int main(int argc, char** argv)
     }
     // ---- damaged files: error code or a mesh whose indices are in range, never a crash ----------------------------
     size_t n_ok = 0, n_err = 0;
-    for (int it = 0; it < 6000; it++) {
-        const Case& c = good[it % 3];
+    const int n_iter = argc > 2 ? std::atoi(argv[2]) : 8000;
+    for (int it = 0; it < n_iter; it++) {
+        const Case& c = good[it % 4];
         std::string b = c.bytes;
         const int kind = (int)(rnd() % 4);
         if (kind == 0) b.resize(rnd() % (b.size() + 1));                                        // truncated
@@ -72,10 +92,11 @@ int main(int argc, char** argv)
             n_ok++;
             for (size_t i = 0; i < 3 * m.n_faces; i++) if (m.faces[i] >= m.n_verts) { std::printf("iteration %d: index out of range in an accepted mesh\n", it); fails++; break; }
             for (size_t i = 0; i < m.n_faces; i++) if (m.face_object_id[i] >= m.n_objects) { std::printf("iteration %d: object id out of range\n", it); fails++; break; }
+            if (m.object_names) for (size_t i = 0; i < m.n_objects; i++) if (!m.object_names[i] || std::strlen(m.object_names[i]) > b.size()) { std::printf("iteration %d: bad object name\n", it); fails++; break; }
             rr_free_mesh(&m);
         } else {
             n_err++;
-            if (m.verts || m.faces || m.face_object_id || !err[0]) { std::printf("iteration %d: a failed load left pointers or no message\n", it); fails++; }
+            if (m.verts || m.faces || m.face_object_id || m.object_names || !err[0]) { std::printf("iteration %d: a failed load left pointers or no message\n", it); fails++; }
         }
     }
     std::printf("damaged files: %zu accepted (indices in range), %zu refused: %s\n", n_ok, n_err, fails ? "FAILED" : "ok");

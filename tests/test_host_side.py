@@ -80,7 +80,7 @@ def test_rr_load_mesh_file_errors(tmp_path):
     with pytest.raises(native.RRError, match="not a PLY"):
         native.load_mesh_file(p)
     with pytest.raises(native.RRError, match="unsupported mesh format"):
-        native.load_mesh_file("scene.dae")
+        native.load_mesh_file("scene.stl")
     with pytest.raises(native.RRError, match="cannot open"):
         native.load_mesh_file(tmp_path / "missing.obj")
     t = tmp_path / "t.ply"
@@ -90,9 +90,135 @@ def test_rr_load_mesh_file_errors(tmp_path):
         native.load_mesh_file(t)
 
 
+DAE_RICH = """<?xml version="1.0" encoding="utf-8"?>
+<!DOCTYPE COLLADA [ <!ENTITY x "y"> ]>
+<!-- every primitive kind, two material groups in one geometry, library nodes, a namespace prefix -->
+<c:COLLADA xmlns:c="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+  <c:asset><c:unit name="inch" meter="0.0254"/><c:up_axis>Z_UP</c:up_axis></c:asset>
+  <c:library_geometries>
+    <c:geometry id="G" name="Hall &amp; &quot;Annex&quot;"><c:mesh>
+      <c:source id="G-pos"><c:float_array id="G-pos-a" count="28">9 9 9 9  7 0 0 0  7 1 0 0  7 1 1 0  7 0 1 0  7 0.5 1.5e0 0  7 -1 .5 +2</c:float_array>
+        <c:technique_common><c:accessor source="#G-pos-a" count="6" stride="4" offset="5"/></c:technique_common></c:source>
+      <c:vertices id="G-v"><c:input semantic="POSITION" source="#G-pos"/></c:vertices>
+      <c:triangles count="2" material="brick"><c:input semantic="NORMAL" source="#none" offset="0"/>
+        <c:input semantic="VERTEX" source="#G-v" offset="1"/><c:p>0 0 0 1 0 2</c:p><c:p> 0 0  0 2  0 3 </c:p></c:triangles>
+      <c:polygons count="1" material="glass"><c:input semantic="VERTEX" source="#G-v" offset="0"/><c:p>0 1 2 3 4</c:p></c:polygons>
+      <c:lines count="1"><c:input semantic="VERTEX" source="#G-v" offset="0"/><c:p>0 1</c:p></c:lines>
+    </c:mesh></c:geometry>
+    <c:geometry id="S"><c:mesh>
+      <c:source id="S-pos"><c:float_array id="S-pos-a" count="18"><![CDATA[0 0 0 1 0 0 1 1 0 0 1 0 0.5 1.5 0 -1 0.5 2]]></c:float_array>
+        <c:technique_common><c:accessor source="#S-pos-a" count="6" stride="3"/></c:technique_common></c:source>
+      <c:vertices id="S-v"><c:input semantic="POSITION" source="#S-pos"/></c:vertices>
+      <c:tristrips count="1"><c:input semantic="VERTEX" source="#S-v" offset="0"/><c:p>0 1 3 2 4</c:p></c:tristrips>
+    </c:mesh></c:geometry>
+    <c:geometry id="F"><c:mesh>
+      <c:source id="F-pos"><c:float_array id="F-pos-a" count="15">0 0 0 1 0 0 1 1 0 0 1 0 -1 1 3</c:float_array>
+        <c:technique_common><c:accessor source="#F-pos-a" count="5" stride="3"/></c:technique_common></c:source>
+      <c:vertices id="F-v"><c:input semantic="POSITION" source="#F-pos"/></c:vertices>
+      <c:trifans count="2"><c:input semantic="VERTEX" source="#F-v" offset="0"/><c:p>0 1 2 3</c:p><c:p>4 3 2 1 0</c:p></c:trifans>
+    </c:mesh></c:geometry>
+    <c:geometry id="Spline"><c:spline/></c:geometry>
+  </c:library_geometries>
+  <c:library_nodes>
+    <c:node id="Prop"><c:rotate>1 1 0 30</c:rotate><c:instance_geometry url="#F"/>
+      <c:node id="PropChild"><c:translate>0 0 1</c:translate><c:instance_geometry url="#S"/></c:node></c:node>
+  </c:library_nodes>
+  <c:library_visual_scenes>
+    <c:visual_scene id="Unused"><c:node><c:instance_geometry url="#S"/></c:node></c:visual_scene>
+    <c:visual_scene id="Main">
+      <c:node id="A"><c:translate>1 2 3</c:translate><c:rotate>0 0 1 45</c:rotate><c:scale>1 2 0.5</c:scale>
+        <c:instance_geometry url="#G"><c:bind_material/></c:instance_geometry>
+        <c:instance_node url="#Prop"/>
+        <c:node id="A1"><c:matrix>0 -1 0 4  1 0 0 5  0 0 1 6  0 0 0 1</c:matrix><c:instance_geometry url="#S"/>
+          <c:instance_geometry url="#Missing"/></c:node>
+        <c:instance_node url="#Prop"/>
+      </c:node>
+      <c:node id="B"><c:lookat>0 0 0 1 1 1 0 0 1</c:lookat><c:instance_geometry url="#F"/><c:instance_geometry url="#Spline"/></c:node>
+    </c:visual_scene>
+  </c:library_visual_scenes>
+  <c:scene><c:instance_visual_scene url="#Main"/></c:scene>
+</c:COLLADA>
+"""
+
+
+def _same_mesh(c, py):
+    assert c["object_names"] == py["object_names"] and c["n_objects"] == len(py["object_names"])
+    assert np.array_equal(c["faces"], py["faces"]) and np.array_equal(c["face_object_id"], py["face_object_id"])
+    # both transform in f64 and round once to f32; numpy's matmul may fuse or reorder the 3-term sums: an ulp of f64
+    # before the rounding, i.e. at most one f32 ulp, and only on a rounding boundary
+    assert np.allclose(c["verts"], py["verts"], rtol=2e-7, atol=1e-7)
+    assert np.mean(c["verts"] == py["verts"]) > 0.99
+
+
+def test_rr_load_mesh_file_collada_equals_meshio(tmp_path):
+    """COLLADA in C (csrc/rr_collada.cpp; the reference's default map is a .dae, launch/mro_husky.launch:4) against
+    meshio.load_dae: the hand-written scene of test_meshio (polylist + triangles, nested nodes, unit), a scene with every
+    primitive kind, several inputs per corner, an accessor with stride 4 / offset 5, two material groups in one geometry,
+    <library_nodes> instantiated twice, a DOCTYPE, a CDATA array, a namespace prefix and entities in a name; and a
+    multi-object scene written by save_dae."""
+    import sys
+    from test_meshio import DAE
+    from common import GOLDEN
+    p = tmp_path / "s.dae"
+    p.write_text(DAE)
+    c = native.load_mesh_file(p)
+    _same_mesh(c, meshio.load_mesh(str(p)))
+    assert c["object_names"] == ["Door", "Wall", "Door"] and c["face_object_id"].tolist() == [0, 1, 1, 2]
+    r = tmp_path / "rich.dae"
+    r.write_text(DAE_RICH)
+    c, py = native.load_mesh_file(r), meshio.load_mesh(str(r))
+    _same_mesh(c, py)
+    # depth-first: A's own geometry (two groups), then its two instance_nodes (Prop: F, then child S) -- before A1 --, then A1, then B
+    assert c["object_names"] == ['Hall & "Annex"[brick]', 'Hall & "Annex"[glass]', "F", "S", "F", "S", "S", "F"]
+    assert np.bincount(c["face_object_id"]).tolist() == [2, 3, 5, 3, 5, 3, 3, 5]
+    sys.path.insert(0, GOLDEN)
+    import gen_oracle_images as gen
+    s = gen.two_room_scene()
+    q = str(tmp_path / "rooms.dae")
+    meshio.save_dae(q, s["verts"], s["faces"], s["face_object_id"])
+    c = native.load_mesh_file(q)
+    _same_mesh(c, meshio.load_mesh(q))
+    order = np.argsort(s["face_object_id"], kind="stable")
+    assert np.array_equal(c["verts"][c["faces"]], s["verts"][s["faces"][order]])
+    assert np.array_equal(c["face_object_id"], s["face_object_id"][order])
+
+
+def test_rr_load_mesh_file_collada_errors(tmp_path):
+    from test_meshio import DAE
+
+    def load(text, name="x.dae"):
+        p = tmp_path / name
+        p.write_text(text)
+        return native.load_mesh_file(p)
+    with pytest.raises(native.RRError, match="not a COLLADA"):
+        load("<html/>")
+    with pytest.raises(native.RRError, match="not well-formed"):
+        load(DAE[:len(DAE) // 2])
+    with pytest.raises(native.RRError, match="not well-formed"):
+        load(DAE.replace("</mesh></geometry>", "</mesh></geometri>", 1))
+    with pytest.raises(native.RRError, match="no visual scene"):
+        load(DAE[:DAE.index("<library_visual_scenes>")] + "</COLLADA>")
+    with pytest.raises(native.RRError, match="out of range"):
+        load(DAE.replace("<p>0 1 2</p>", "<p>0 1 3</p>"))
+    with pytest.raises(native.RRError, match="out of range"):
+        load(DAE.replace("<p>0 1 2</p>", "<p>0 -1 2</p>"))
+    with pytest.raises(native.RRError, match="malformed <translate>"):
+        load(DAE.replace("<translate>10 0 0</translate>", "<translate>10 0</translate>"))
+    with pytest.raises(native.RRError, match="no triangle geometry"):
+        load(DAE.replace('url="#Door-mesh"', 'url="#Nothing"').replace('url="#Wall-mesh"', 'url="#Nothing"'))
+    # an instance_node that reaches itself: refused, not followed for ever
+    cyc = DAE.replace("<library_visual_scenes>", '<library_nodes><node id="L"><instance_geometry url="#Door-mesh"/>'
+                      '<instance_node url="#L"/><instance_node url="#L"/></node></library_nodes><library_visual_scenes>')
+    cyc = cyc.replace('<node id="Door" name="Door">', '<node id="Door" name="Door"><instance_node url="#L"/>')
+    with pytest.raises(native.RRError, match="too deep|too large|more triangles"):
+        load(cyc)
+    with pytest.raises(ValueError):
+        meshio.load_mesh(str(tmp_path / "x.dae"))
+
+
 def test_host_side_under_asan(tmp_path):
-    """csrc/rr_host.cpp under AddressSanitizer + UBSan (CPU; it has no GPU code): the sampler's unit vectors and argument
-    checks, the three well-formed files, and 6,000 damaged ones (truncated, bytes flipped, digits inserted into counts and
+    """csrc/rr_host.cpp + rr_collada.cpp under AddressSanitizer + UBSan (CPU; no GPU code): the sampler's unit vectors and
+    argument checks, the four well-formed files (PLY ascii / binary, OBJ, COLLADA), and 8,000 damaged ones (truncated, bytes flipped, digits inserted into counts and
     indices, bytes removed) -- every load ends in an error code or in a mesh whose indices are in range, never in a crash
     (found on the first run: an inflated vertex count reserved 490 GB; counts are now bounded by the file's size)."""
     import os
@@ -104,7 +230,8 @@ def test_host_side_under_asan(tmp_path):
     exe = str(tmp_path / "host_side_check")
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                     "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "host_side_check.cpp"),
-                    os.path.join(root, "radarays_ros_amd", "csrc", "rr_host.cpp"), "-o", exe], check=True)
+                    os.path.join(root, "radarays_ros_amd", "csrc", "rr_host.cpp"),
+                    os.path.join(root, "radarays_ros_amd", "csrc", "rr_collada.cpp"), "-o", exe], check=True)
     work = tmp_path / "files"
     work.mkdir()
     r = subprocess.run([exe, str(work)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
