@@ -122,6 +122,16 @@ struct rr_multi {
 
 namespace {
 
+void stop_workers(rr_multi* m)
+{
+    for (auto& w : m->workers) {
+        { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
+    m->workers.clear();
+}
+
 int mfail(rr_multi* m, int code, const std::string& msg) { if (m) m->err = msg; else g_multi_create_error = msg; return code; }
 
 #define RRM_HIP(m, expr)                                                                       \
@@ -207,7 +217,7 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
                         w->cv.notify_all();
                     }
                 });
-            } catch (...) { m->workers.clear(); break; }       // no thread to be had: the caller's thread does the work
+            } catch (...) { stop_workers(m); break; }          // no thread to be had: the caller's thread does the work
         }
     }
     if ((n_devices > 1 && !loopback) || m->self_rccl) {
@@ -223,12 +233,7 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
 void rr_destroy_multi(rr_multi* m)
 {
     if (!m) return;
-    for (auto& w : m->workers) {
-        { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
-        w->cv.notify_all();
-        if (w->th.joinable()) w->th.join();
-    }
-    m->workers.clear();
+    stop_workers(m);
     for (size_t i = 0; i < m->ctx.size(); i++) { (void)hipSetDevice(m->devices[i]); (void)hipDeviceSynchronize(); }
     for (size_t i = 0; i < m->comms.size(); i++) if (m->comms[i]) g_rccl.CommDestroy(m->comms[i]);
     for (MultiSlot& S : m->slots) {
