@@ -175,6 +175,22 @@ def test_environment_switches_are_documented():
     assert listed - used == set(), "documented but unused: %s" % sorted(listed - used)
 
 
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md (the reference-side binding a maintainer would add) has a row for every function the header declares
+    -- literally, or through the table's shorthands `rr_multi_set_*`, `name[_suffix]`."""
+    import re
+    header = open(os.path.join(ROOT, "include", "radarays_mi355.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", header))
+    named = set(re.findall(r"rr_[a-z0-9_]+", doc))
+    for base, opt in re.findall(r"(rr_[a-z0-9_]+)\[(_[a-z0-9_]+)\]", doc):      # rr_simulate_param_sets[_device]
+        named.add(base + opt)
+    for base, opt, tail in re.findall(r"(rr_[a-z0-9_]+)\[(_[a-z0-9_]+)\](_[a-z0-9_]+)", doc):   # rr_multi_simulate[_batch]_async
+        named.add(base + opt + tail); named.add(base + tail)
+    missing = sorted(d for d in declared if d not in named and not (d.startswith("rr_multi_set_") and "rr_multi_set_*" in doc))
+    assert missing == [], "no row in INTEGRATION.md: %s" % missing
+
+
 def test_bench_refuses_more_gpus_than_the_box_has_at_once():
     """`python bench.py --gpus 8` (no launcher): the parent counts devices WITHOUT touching the GPU, and where there are
     fewer than asked for it exits non-zero with one clear line instead of starting ranks that would fail one by one."""
