@@ -736,3 +736,29 @@ def test_differential_fuzz_motion_denoisers_azimuth_counts(native_lib, oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz_diff2
     assert fuzz_diff2.run(n=12, seed=42, verbose=False) == 0
+
+
+def test_collada_map_file_through_the_c_loader(native_lib, oracle, tmp_path):
+    """The node's map route (rm::import_embree_map, radar_simulator.cpp:149; default map `oru4.dae`,
+    launch/mro_husky.launch:4): a multi-object scene written as COLLADA, read back by rr_load_mesh_file (C), its object
+    names matched against the material table as the header tells the adapter to, rendered, and compared with the oracle
+    on the loaded arrays -- and with the frame of the original arrays (the file groups the faces by object, which
+    cannot change a nearest hit)."""
+    from radarays_ros_amd import meshio
+    s = gen.two_room_scene()
+    p = str(tmp_path / "rooms.dae")
+    names = ["room", "slab"][:int(s["face_object_id"].max()) + 1]
+    meshio.save_dae(p, s["verts"], s["faces"], s["face_object_id"], object_names=names)
+    m = native_lib.load_mesh_file(p)
+    assert m["n_objects"] == len(names) and m["object_names"] == names
+    table = {names[i]: int(s["object_materials"][i]) for i in range(len(names))}     # scene object name -> material id
+    loaded = {"verts": m["verts"], "faces": m["faces"], "face_object_id": m["face_object_id"],
+              "object_materials": np.asarray([table[n] for n in m["object_names"]], np.int32)}
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=0)
+    pose = scenes.default_pose("box12")
+    _, g8, _ = _check(native_lib, oracle, loaded, cfg, mats, golden_beams(48), pose, (0, 128), use_bvh=0)
+    c = _ctx(native_lib, s, cfg, mats, golden_beams(48))
+    o8, _, _ = c.simulate(pose, 0, 128)
+    c.close()
+    assert np.array_equal(g8, o8)
