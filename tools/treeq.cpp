@@ -7,6 +7,8 @@
 //   python tools/treeq_dump.py <config id> <passes> <out dir>     (scene + rays: the oracle's ORC_RAYLOG)
 //   g++ -O2 -std=c++17 -ffp-contract=off -I radarays_ros_amd/csrc tools/treeq.cpp radarays_ros_amd/csrc/rr_bvh.cpp -o /tmp/treeq -lpthread
 //   RR_BVH_ALPHA=1e-5 RR_BVH_BUDGET=1 /tmp/treeq <out dir>
+//   TREEQ_CULL_POP=1: with the later passes' cull at pop time; TREEQ_PREDICT / TREEQ_SORTED: ray-order studies; TREEQ_SLAB: an extra
+//   pair of planes per child (all of them studies whose results are in DESIGN_EXPERIMENTS.md)
 #include "rr_bvh.h"
 
 #include <algorithm>
@@ -36,6 +38,12 @@ static std::vector<T> slurp(const std::string& path)
 struct RayRec { int32_t az, pass; float o[3], d[3]; uint32_t parent, mat; };
 struct Cost { unsigned nodes = 0, leaves = 0, tris = 0; float t = -1.f; uint32_t face = 0xFFFFFFFFu; unsigned nh[5] = {0,0,0,0,0}; unsigned leaves_after_hit = 0, nodes_after_hit = 0; };
 
+// experiment (TREEQ_SLAB): one more pair of planes per child -- normal n (area-weighted mean normal of the subtree's
+// triangles), [smin, smax] = extent of n . p over the subtree's triangles clipped to the child's box
+struct Slab { float n[3]; float smin, smax; };
+static std::vector<Slab> g_slab;       // [node][4]
+static bool g_use_slab = false;
+
 static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range_max)
 {
     Cost c;
@@ -60,6 +68,14 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
                 for (int k = 0; k < 3; k++) {
                     const float a = std::fma(ch.lo[k], inv[k], oo[k]), b = std::fma(ch.hi[k], inv[k], oo[k]);
                     tn = std::max(tn, std::min(a, b)); tf = std::min(tf, std::max(a, b));
+                }
+                if (g_use_slab && ch.ref != kEmptyRef) {
+                    const Slab& sl = g_slab[(size_t)cur * 4 + q];
+                    const float dn = sl.n[0] * d[0] + sl.n[1] * d[1] + sl.n[2] * d[2], on = sl.n[0] * o[0] + sl.n[1] * o[1] + sl.n[2] * o[2];
+                    if (std::fabs(dn) > 1e-12f) {
+                        const float a = (sl.smin - on) / dn, b = (sl.smax - on) / dn;
+                        tn = std::max(tn, std::min(a, b)); tf = std::min(tf, std::max(a, b));
+                    } else if (on < sl.smin || on > sl.smax) tf = -1.f;
                 }
                 if (tn <= std::min(tf, tcull) && ch.ref != kEmptyRef) {
                     uint32_t bits; memcpy(&bits, &tn, 4);
@@ -129,6 +145,60 @@ int main(int argc, char** argv)
            B.nodes.size(), B.tris.size(), (double)B.tris.size() / (faces.size() / 3), B.depth, B.stack_need,
            (unsigned long long)B.spatial_splits, B.sah_cost, B.build_seconds);
 
+    if (getenv("TREEQ_SLAB")) {
+        g_slab.assign(B.nodes.size() * 4, Slab{ { 0, 0, 1 }, -INFINITY, INFINITY });
+        const float pad = B.inflate;
+        // pass 1: area-weighted normal sum per child (post-order); pass 2: extents along the chosen normal
+        std::vector<double> nsum(B.nodes.size() * 4 * 3, 0.0);
+        struct Rec { static void sum(const Bvh4& B, uint32_t ref, double out[3], std::vector<double>& nsum) {
+            out[0] = out[1] = out[2] = 0;
+            if (ref & kLeafFlag) {
+                const uint32_t first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+                for (uint32_t i = 0; i < cnt; i++) { const TriRec& T = B.tris[first + i];
+                    double n[3] = { (double)T.e1[1] * T.e2[2] - (double)T.e1[2] * T.e2[1], (double)T.e1[2] * T.e2[0] - (double)T.e1[0] * T.e2[2], (double)T.e1[0] * T.e2[1] - (double)T.e1[1] * T.e2[0] };
+                    // orient consistently (upper hemisphere, then +x, +y) so that the two sides of a wall do not cancel
+                    if (n[2] < 0 || (n[2] == 0 && (n[0] < 0 || (n[0] == 0 && n[1] < 0)))) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+                    for (int k = 0; k < 3; k++) out[k] += n[k]; }
+                return;
+            }
+            const Node4& n = B.nodes[ref];
+            for (int q = 0; q < 4; q++) { if (n.c[q].ref == kEmptyRef) continue; double s[3]; sum(B, n.c[q].ref, s, nsum);
+                for (int k = 0; k < 3; k++) { nsum[((size_t)ref * 4 + q) * 3 + k] = s[k]; out[k] += s[k]; } }
+        }
+        static void ext(const Bvh4& B, uint32_t ref, const float n[3], const float lo[3], const float hi[3], float& mn, float& mx) {
+            if (ref & kLeafFlag) {
+                const uint32_t first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+                for (uint32_t i = 0; i < cnt; i++) { const TriRec& T = B.tris[first + i];
+                    float a = INFINITY, b = -INFINITY;
+                    for (int v = 0; v < 3; v++) { float p[3]; for (int k = 0; k < 3; k++) p[k] = T.v0[k] + (v == 1 ? T.e1[k] : v == 2 ? T.e2[k] : 0.f);
+                        const float sdot = n[0] * p[0] + n[1] * p[1] + n[2] * p[2]; a = std::min(a, sdot); b = std::max(b, sdot); }
+                    mn = std::min(mn, a); mx = std::max(mx, b); }
+                return;
+            }
+            const Node4& nd = B.nodes[ref];
+            for (int q = 0; q < 4; q++) if (nd.c[q].ref != kEmptyRef) ext(B, nd.c[q].ref, n, lo, hi, mn, mx);
+        } };
+        double tot[3]; Rec::sum(B, 0, tot, nsum);
+        size_t done = 0;
+        for (size_t ni = 0; ni < B.nodes.size(); ni++) for (int q = 0; q < 4; q++) {
+            const Child4& ch = B.nodes[ni].c[q];
+            if (ch.ref == kEmptyRef) continue;
+            double* sN = &nsum[(ni * 4 + q) * 3];
+            if (ch.ref & kLeafFlag) { double t3[3]; Rec::sum(B, ch.ref, t3, nsum); sN[0] = t3[0]; sN[1] = t3[1]; sN[2] = t3[2]; }
+            const double len = std::sqrt(sN[0] * sN[0] + sN[1] * sN[1] + sN[2] * sN[2]);
+            Slab& sl = g_slab[ni * 4 + q];
+            if (len <= 0) continue;
+            for (int k = 0; k < 3; k++) sl.n[k] = (float)(sN[k] / len);
+            float mn = INFINITY, mx = -INFINITY;
+            Rec::ext(B, ch.ref, sl.n, ch.lo, ch.hi, mn, mx);
+            // the box's own extent along n bounds the clipped references
+            float bmn = 0, bmx = 0; for (int k = 0; k < 3; k++) { bmn += sl.n[k] * (sl.n[k] >= 0 ? ch.lo[k] : ch.hi[k]); bmx += sl.n[k] * (sl.n[k] >= 0 ? ch.hi[k] : ch.lo[k]); }
+            sl.smin = std::max(mn, bmn) - pad; sl.smax = std::min(mx, bmx) + pad;
+            done++;
+        }
+        g_use_slab = true;
+        printf("slabs: %zu children\n", done);
+    }
     // optional cross-check of the hits against a reference file written by an earlier run
     std::vector<uint32_t> ref_face; std::vector<float> ref_t;
     if (FILE* f = fopen((dir + "/hits.ref").c_str(), "rb")) {
