@@ -36,7 +36,7 @@ static std::vector<T> slurp(const std::string& path)
 }
 
 struct RayRec { int32_t az, pass; float o[3], d[3]; uint32_t parent, mat; };
-struct Cost { unsigned nodes = 0, leaves = 0, tris = 0; float t = -1.f; uint32_t face = 0xFFFFFFFFu; unsigned nh[5] = {0,0,0,0,0}; unsigned leaves_after_hit = 0, nodes_after_hit = 0; };
+struct Cost { unsigned merged = 0; unsigned nodes = 0, leaves = 0, tris = 0; float t = -1.f; uint32_t face = 0xFFFFFFFFu; unsigned nh[5] = {0,0,0,0,0}; unsigned leaves_after_hit = 0, nodes_after_hit = 0; };
 
 // experiment (TREEQ_SLAB): one more pair of planes per child -- normal n (area-weighted mean normal of the subtree's
 // triangles), [smin, smax] = extent of n . p over the subtree's triangles clipped to the child's box
@@ -57,9 +57,12 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
     uint32_t cur = 0;
     float best_t = INFINITY; uint32_t best_face = 0xFFFFFFFFu;
     float tcull = range_max * 1.0001f + 1e-3f;
+    bool after_leaf = false;       // TREEQ_MERGE study: a node step that directly follows a leaf step (always through a pop) could share its iteration
     while (true) {
         if (!(cur & kLeafFlag)) {
             c.nodes++;
+            if (after_leaf) c.merged++;
+            after_leaf = false;
             const Node4& n = B.nodes[cur];
             uint32_t key[4]; uint32_t ref[4]; int nh = 0;
             for (int q = 0; q < 4; q++) {
@@ -92,6 +95,7 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
                 continue;
             }
         } else {
+            after_leaf = true;
             c.leaves++;
             if (best_face != 0xFFFFFFFFu) c.leaves_after_hit++;
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
@@ -261,17 +265,19 @@ int main(int argc, char** argv)
     std::map<int, std::vector<size_t>> by_pass;
     for (size_t i = 0; i < rays.size(); i++) by_pass[rays[i].pass].push_back(i);
     double tn = 0, tl = 0, tt = 0, tw = 0; size_t tr = 0, twv = 0;
+    double merged_all = 0, wave_merged = 0;
     for (auto& kv : by_pass) {
         double n = 0, l = 0, t = 0, wave_steps = 0; size_t waves = 0;
         const auto& idx = kv.second;
         for (size_t k = 0; k < idx.size(); k += 16) {
             unsigned mx = 0; int az = rays[idx[k]].az;
             size_t e = k;
-            for (; e < std::min(idx.size(), k + 16) && rays[idx[e]].az == az; e++) mx = std::max(mx, cost[idx[e]].nodes + cost[idx[e]].leaves);
-            wave_steps += mx; waves++;
+            unsigned mxm = 0;
+            for (; e < std::min(idx.size(), k + 16) && rays[idx[e]].az == az; e++) { mx = std::max(mx, cost[idx[e]].nodes + cost[idx[e]].leaves); mxm = std::max(mxm, cost[idx[e]].nodes + cost[idx[e]].leaves - cost[idx[e]].merged); }
+            wave_steps += mx; waves++; wave_merged += mxm;
             if (e < k + 16 && e < idx.size()) k = e - 16;   // azimuth boundary: next wave starts at e
         }
-        for (size_t i : idx) { n += cost[i].nodes; l += cost[i].leaves; t += cost[i].tris; }
+        for (size_t i : idx) { n += cost[i].nodes; l += cost[i].leaves; t += cost[i].tris; merged_all += cost[i].merged; }
         const double m = (double)idx.size();
         printf("pass %d: %8zu rays  nodes/ray %6.2f  leaves/ray %5.2f  tris/ray %6.2f  steps/ray %6.2f  wave iterations (est.) %6.2f  bytes/ray %7.1f\n",
                kv.first, idx.size(), n / m, l / m, t / m, (n + l) / m, wave_steps / waves, (n * 128 + t * 48) / m + 132);
@@ -326,6 +332,8 @@ int main(int argc, char** argv)
         }
         printf("rays sorted by true cost inside each (azimuth, pass): wave iterations %.2f\n", ws / nw);
     }
+    if (getenv("TREEQ_MERGE")) printf("leaf step + the node step popped after it in ONE iteration: %.2f merges per ray, steps/ray %.2f -> %.2f, wave iterations (est.) %.2f -> %.2f\n",
+                                      merged_all / tr, (tn + tl) / tr, (tn + tl - merged_all) / tr, tw / twv, wave_merged / twv);
     printf("all   : %8zu rays  nodes/ray %6.2f  leaves/ray %5.2f  tris/ray %6.2f  steps/ray %6.2f  wave iterations (est.) %6.2f  bytes/ray %7.1f\n",
            tr, tn / tr, tl / tr, tt / tr, (tn + tl) / tr, tw / twv, (tn * 128 + tt * 48) / tr + 132);
     return mism ? 1 : 0;
