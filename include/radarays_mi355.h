@@ -147,11 +147,13 @@ int rr_set_beam_samples(rr_ctx* ctx, const float* dirs /*[n][3]*/, size_t n);
  * the batch entry points n may be k * n_angles (k >= 2 rows), frame f of a batch then uses row f % k. */
 int rr_set_noise_offsets(rr_ctx* ctx, const float* rnd, size_t n);
 
-/* include_motion = true (RadarCPU.cpp:190-196, cfg/RadarModel.cfg:85): the reference looks
+/* include_motion = true (RadarCPU.cpp:190-196, cfg/RadarModel.cfg:85 -- the .cfg default): the reference looks
  * Tsm up once PER AZIMUTH.  poses = [n_angles][7] (qx,qy,qz,qw,tx,ty,tz); while set, every
  * rr_simulate* call uses poses[azimuth] and ignores its own pose argument (which must still
- * be a valid pose).  n = 0 switches back to one pose per frame.  A pose batch
- * (rr_simulate_batch_columns_device with n_frames > 1) is refused while a table is set. */
+ * be a valid pose).  n = 0 switches back to one pose per frame.  For the batch entry points n may be
+ * k * n_angles (k tables, one sweep of the antenna each): frame f of a batch then uses table f % k, like the
+ * rows of rr_set_noise_offsets -- the reference's default mode through the batched / multi-GPU path.  (A parameter
+ * batch renders every set with table 0.) */
 int rr_set_motion_poses(rr_ctx* ctx, const float* poses, size_t n);
 
 /* RadarCPU::simulate for azimuths [az_begin, az_end) with sensor pose

@@ -127,6 +127,7 @@ struct rr_ctx {
     std::vector<float> beams;   // xyz
     std::vector<float> noise;
     int noise_rows = 1;
+    int motion_rows = 1;
     std::vector<float> motion;   // [n_angles][7] or empty
     std::vector<float> smear;
     int smear_mode = 0;
@@ -375,7 +376,10 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, hipMemcpy(c->d_noise.p, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if ((dirty & (rr_ctx::D_MOTION | rr_ctx::D_CFG)) && !c->motion.empty()) {
-        if (c->motion.size() != 7 * (size_t)g.n_angles) return fail(c, -3, "rr_set_motion_poses: need n_angles poses");
+        // one table of n_angles poses, or k tables: frame f of a batch then takes table f % k (one sweep of the antenna per frame)
+        if (c->motion.size() % (7 * (size_t)g.n_angles) != 0)
+            return fail(c, -3, "rr_set_motion_poses: the number of poses must be a multiple of n_angles (one table per frame of a batch)");
+        c->motion_rows = (int)(c->motion.size() / (7 * (size_t)g.n_angles));
         RR_HIP(c, c->d_motion.ensure(c->motion.size()));
         RR_HIP(c, hipMemcpy(c->d_motion.p, c->motion.data(), c->motion.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -466,7 +470,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.object_materials = c->d_objmat.p; P.smear = c->d_smear.p;
     P.noise_rnd = g.ambient_noise ? c->d_noise.p : nullptr; P.noise_rows = c->noise_rows;
     P.decay = c->d_decay.p;
-    P.motion_poses = c->motion.empty() ? nullptr : c->d_motion.p;
+    P.motion_poses = c->motion.empty() ? nullptr : c->d_motion.p; P.motion_rows = c->motion_rows;
     for (int k = 0; k < 2; k++) {
         P.waves[k].A = L.d_wA[k].p; P.waves[k].B = L.d_wB[k].p; P.waves[k].C = L.d_wC[k].p;
         P.idx[k] = L.d_idx[k].p; P.count[k] = L.d_count[k].p; P.torder[k] = L.d_torder[k].p;
@@ -576,8 +580,6 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     const int n_seg = n_loc * n_frames;
     if (n_seg == 0) return 0;
     if (n_frames < 1 || n_frames > RR_MAX_BATCH) return fail(c, -3, "frame batch must be 1..64");
-    if (n_frames > 1 && !d_matsets && !c->motion.empty())
-        return fail(c, -3, "a batch of poses cannot be combined with rr_set_motion_poses (one pose table per azimuth sweep): render such frames one by one");
     for (int k = 0; k < 7 * (d_matsets ? 1 : n_frames); k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
     int rc = upload_tables(c); if (rc) return rc;
     rc = prepare_lane(c, L, n_seg, lane_f32); if (rc) return rc;
@@ -590,6 +592,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         P.materials = d_matsets; P.mat_limits = L.d_matset_limits.p; P.mat_stride = mat_stride;
         P.set_mode = 1;
         P.noise_rows = 1;     // every set is the SAME frame under another parameter set: one noise realisation (row 0)
+        P.motion_rows = 1;    // ... and one sweep of the antenna (table 0)
         for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[k];
         SetPlan dflt;
         if (!plan) {          // material sets only: one beam, every frame the config's passes

@@ -114,7 +114,8 @@ struct Params {
     unsigned char frame_beam[64];     // set_mode: group (= beam table) of frame f
     unsigned char group_frame[64];    // set_mode: the frame whose segments pass 0 of group g is traced for
     const float* decay;          // [n_cells] expf(-energy_loss * bin range), ambient noise floor
-    const float* motion_poses;   // [n_angles][7] per-azimuth Tsm (include_motion) or null
+    const float* motion_poses;   // [motion_rows][n_angles][7] per-azimuth Tsm (include_motion) or null; frame f of a batch reads table f % motion_rows
+    int motion_rows;
     // frame state
     WaveBuf waves[2];            // [n_seg][2*cap] child slots, ping-pong by pass parity
     uint32_t* idx[2];            // [n_seg][cap] live slot list

@@ -35,7 +35,7 @@ __device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t
         q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
     }
     if (P.motion_poses) {     // include_motion: Tsm looked up per azimuth (RadarCPU.cpp:190-196)
-        const float* ps = P.motion_poses + 7 * (size_t)az;
+        const float* ps = P.motion_poses + 7 * ((size_t)(frame % P.motion_rows) * P.n_angles + az);
         q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
     }
     q_am = q_mul(q_sm, q_as);

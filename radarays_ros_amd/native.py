@@ -279,7 +279,8 @@ class Context:
         self._ck(self._L.rr_set_noise_offsets(self._h, r.ctypes.data, r.size))
 
     def set_motion_poses(self, poses):
-        """include_motion: [n_angles][7] per-azimuth poses; None/empty switches it off."""
+        """include_motion: [n_angles][7] per-azimuth poses, or [k][n_angles][7] (frame f of a batch uses table f % k);
+        None/empty switches it off."""
         if poses is None or len(poses) == 0:
             self._ck(self._L.rr_set_motion_poses(self._h, None, 0))
             return
@@ -604,6 +605,14 @@ class MultiContext:
     def set_noise_offsets(self, rnd):
         r = np.ascontiguousarray(rnd, np.float32).ravel()
         self._ck(self._L.rr_multi_set_noise_offsets(self._h, r.ctypes.data, r.size))
+
+    def set_motion_poses(self, poses):
+        """include_motion on every device: [n_angles][7], or [k][n_angles][7] (one table per frame of a batch); None: off."""
+        if poses is None or len(poses) == 0:
+            self._ck(self._L.rr_multi_set_motion_poses(self._h, None, 0))
+            return
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ck(self._L.rr_multi_set_motion_poses(self._h, p.ctypes.data, len(p)))
 
     def simulate_batch(self, poses):
         """-> uint8 [n][n_cells][n_angles] in host memory."""

@@ -100,9 +100,40 @@ def kaist_preset(**kw) -> RadarModelConfig:
     return c.copy(**kw)
 
 
+def laserlike_preset(**kw) -> RadarModelConfig:
+    """cfg/mulran_kaist_dyncfg_laserlike.yaml: ONE ray per azimuth (beam_width 1e-4 deg, D1), one pass, no smear kernel
+    (signal_denoising 0: slice[bin] = max(slice[bin], I), RadarCPU.cpp:438-446), no ambient noise -- the radar as a 2D
+    laser scanner."""
+    c = kaist_preset(ambient_noise=0, beam_sample_dist=0, beam_sample_dist_normal_p_in_cone=0.999, beam_width=0.0001,
+                     energy_min=0.72, n_reflections=1, n_samples=1, signal_denoising=0)
+    return c.copy(**kw)
+
+
+def minimal_preset(**kw) -> RadarModelConfig:
+    """cfg/mulran_kaist_dyncfg_minimal.yaml: 10 samples in a 2 degree beam, smear kernel W = 23 with mode 0.1
+    (-> int(0.1 * 23) = 2, RadarCPU.cpp:57), weaker noise.  The file holds neither include_motion nor signal_max: what
+    `dynparam load` does not set keeps the .cfg default (True, 120)."""
+    c = kaist_preset(ambient_noise_at_signal_0=0.05, ambient_noise_at_signal_1=0.01, ambient_noise_energy_max=0.08,
+                     beam_sample_dist_normal_p_in_cone=0.99, beam_width=2.0, n_samples=10,
+                     signal_denoising_triangular_mode=0.1, signal_denoising_triangular_width=23,
+                     include_motion=True, signal_max=120.0)
+    return c.copy(**kw)
+
+
 def kaist_materials() -> List[RadarMaterial]:
     """config/mulran_kaist02.yaml:8-20 (air, wall stone)."""
     return [RadarMaterial(0.3, 1.0, 0.0, 1.0), RadarMaterial(0.0, 1.0, 0.0, 3000.0)]
+
+
+def oru4_test_materials() -> List[RadarMaterial]:
+    """config/oru4_test.yaml:8-33: air, wall stone, shelf wood, window glass (v = 0.03: refracts), metal."""
+    return [RadarMaterial(0.3, 1.0, 0.0, 1.0), RadarMaterial(0.0, 1.0, 0.0, 3000.0), RadarMaterial(0.0, 1.0, 0.0, 1.0),
+            RadarMaterial(0.03, 1.0, 0.0, 100.0), RadarMaterial(0.0, 1.0, 0.0, 1.0)]
+
+
+# config/oru4_test.yaml:37-56 (the same list closes config/mulran_kaist02.yaml:24-43): material of each of the 18 objects
+# of the ORU4 scene, in the order rmagine numbers the geometries of the .dae (ground, door glass, wall, door wood, ...)
+ORU4_OBJECT_MATERIALS = [1, 3, 1, 2, 3, 3, 2, 2, 3, 3, 2, 2, 4, 2, 4, 2, 4, 1]
 
 
 # SURVEY.md §8d config 3: one penetrable material so that Snell/Fresnel splitting
