@@ -126,6 +126,55 @@ def heightfield_room(n_quads, extent=420.0, z_lo=-6.0, z_hi=24.0, n_buildings=0,
             "name": "heightfield%d_b%d" % (n_quads, n_buildings)}
 
 
+# The 18 objects config/oru4_test.yaml:37-56 lists for the ORU4 scene (the .dae itself is author-local,
+# launch/mro_husky.launch:4): their names, in the order the reference's object_materials table indexes them
+ORU4_OBJECT_NAMES = ["HallwayGround", "DoorHallway1Glass", "HallwayWall", "DoorT1203Wood", "DoorT1203Glass", "DoorT1210Glass",
+                     "DoorT1210Wood", "DoorFikaWood", "DoorFikaGlass", "DoorLabGlass", "Bookshelf2", "Bookshelf", "Locker",
+                     "Workbench2", "Locker2", "Workbench", "Trash", "Building"]
+
+
+def oru4_like_scene():
+    """A stand-in for the reference's ORU4 office scene with the SAME 18 objects in the same order, so that
+    config/oru4_test.yaml's object_materials table (5 materials; glass v = 0.03 refracts) applies as it is: a 24 x 3 m
+    hallway inside a closed building shell, wall segments with door openings, wood doors with glass panes, glass doors,
+    shelves, lockers, workbenches, a trash bin.  Every object is a few axis-aligned boxes (the real mesh is not in the
+    repository); the sensor stands at (1.0, 1.5, 0.2 + ...) in free space."""
+    parts = {n: [] for n in ORU4_OBJECT_NAMES}
+
+    def box(name, lo, hi):
+        parts[name].append((lo, hi))
+    box("Building", (-14.0, -9.0, -1.0), (14.0, 9.0, 4.0))                 # closed shell: every ray ends somewhere
+    box("HallwayGround", (-13.5, -8.5, -0.6), (13.5, 8.5, -0.5))
+    # the hallway runs along x at y in [0, 3]; its two walls have door openings
+    for x0, x1 in ((-12.0, -7.0), (-5.8, -1.0), (0.2, 4.0), (5.2, 12.0)):
+        box("HallwayWall", (x0, 3.0, -0.5), (x1, 3.2, 2.6))
+    for x0, x1 in ((-12.0, -4.0), (-2.8, 6.0), (7.2, 12.0)):
+        box("HallwayWall", (x0, -0.2, -0.5), (x1, 0.0, 2.6))
+    box("HallwayWall", (-12.2, -0.2, -0.5), (-12.0, 3.2, 2.6))
+    # doors in the openings of the far wall (y = 3.0 .. 3.2): wood leaf with a glass pane above the handle
+    box("DoorT1203Wood", (-7.0, 3.04, -0.5), (-5.8, 3.12, 0.9));  box("DoorT1203Glass", (-7.0, 3.06, 0.9), (-5.8, 3.10, 2.1))
+    box("DoorT1210Wood", (-1.0, 3.04, -0.5), (0.2, 3.12, 0.9));   box("DoorT1210Glass", (-1.0, 3.06, 0.9), (0.2, 3.10, 2.1))
+    box("DoorFikaWood", (4.0, 3.04, -0.5), (5.2, 3.12, 0.9));     box("DoorFikaGlass", (4.0, 3.06, 0.9), (5.2, 3.10, 2.1))
+    # all-glass doors: the near wall's openings and the end of the hallway
+    box("DoorLabGlass", (-4.0, -0.13, -0.5), (-2.8, -0.07, 2.1))
+    box("DoorHallway1Glass", (12.0, 0.0, -0.5), (12.06, 3.0, 2.3))
+    # furniture in the rooms behind the walls and along the hallway
+    box("Bookshelf", (-11.5, 6.0, -0.5), (-8.5, 6.4, 1.7));       box("Bookshelf2", (-3.0, 7.2, -0.5), (0.5, 7.6, 1.9))
+    box("Locker", (6.4, 0.05, -0.5), (7.0, 0.5, 1.4));            box("Locker2", (8.0, 5.0, -0.5), (8.6, 6.2, 1.4))
+    box("Workbench", (2.0, 5.0, -0.5), (4.5, 5.9, 0.4));          box("Workbench2", (-9.0, -6.0, -0.5), (-6.0, -5.0, 0.4))
+    box("Trash", (3.1, 0.1, -0.5), (3.5, 0.5, 0.1))
+    verts, faces, obj = [], [], []
+    vb = 0
+    for oid, name in enumerate(ORU4_OBJECT_NAMES):
+        assert parts[name], name
+        for lo, hi in parts[name]:
+            v, f = _box_tris(lo, hi, vbase=vb)
+            verts.append(v); faces.append(f); obj.append(np.full(len(f), oid, np.uint32))
+            vb += 8
+    return {"verts": np.concatenate(verts).astype(np.float32), "faces": np.concatenate(faces).astype(np.uint32),
+            "face_object_id": np.concatenate(obj), "object_names": list(ORU4_OBJECT_NAMES), "name": "box12_oru4_like"}
+
+
 # BASELINE.json configs -> scene recipes (SURVEY §8d)
 def config_scene(config_id):
     if config_id == 1:

@@ -130,3 +130,140 @@ def test_include_motion_through_rr_multi(native_lib, motion_case, monkeypatch, n
     m.set_motion_poses(None)
     assert not np.array_equal(m.simulate(sweeps[0][0]), got[0])
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's OWN parameter sets as named parity cases: each preset of cfg/*.yaml and the material
+# table of config/oru4_test.yaml, values as tests/test_ref_presets.py pins them to the files, rendered for all 400
+# azimuths against the oracle.  Beams are drawn the way RadarCPU.cpp:136-145 asks for them (sample_cone_local with the
+# preset's width / count / distribution; seeded).
+# ---------------------------------------------------------------------------------------------------------------------
+U8_MISMATCH_TOL = 1e-3
+
+
+def _beam_of(native_lib, cfg, seed=42):
+    import math
+    return native_lib.sample_cone_local(seed, cfg.beam_width * math.pi / 180.0, cfg.n_samples, cfg.beam_sample_dist,
+                                        cfg.beam_sample_dist_normal_p_in_cone)
+
+
+def _render_and_compare(native_lib, oracle, s, cfg, mats, objmat, beams, pose, noise=None, use_bvh=1):
+    c = native_lib.Context(0)
+    c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    c.set_materials(mats, objmat, 0)
+    c.set_config(cfg)
+    c.set_beam_samples(beams)
+    if noise is not None:
+        c.set_noise_offsets(noise)
+    motion = np.ndim(pose) == 2
+    if motion:
+        c.set_motion_poses(pose)
+    g8, gf, gst = c.simulate(pose[0] if motion else pose, want_f32=True)
+    sc = oracle.Scene(s["verts"], s["faces"], s["face_object_id"], use_bvh=use_bvh)
+    o8, of, ost = oracle.simulate(sc, mats_tuple(mats), objmat, cfg, beams, pose, noise_rnd=noise)
+    assert gst["overflow"] == 0
+    for k in ("wave_passes", "hits", "signals"):
+        assert gst[k] == ost[k], (k, gst, ost)
+    d = image_diff(gf, of, g8, o8)
+    assert d["mean_dev"] <= MEAN_DEV_TOL and d["u8_max"] <= 1 and d["u8_mismatch_frac"] <= U8_MISMATCH_TOL, d
+    c.close()
+    return g8, gst
+
+
+@pytest.mark.parametrize("scene_id", ["two_rooms", "config2", "buildings"])
+def test_preset_laserlike(native_lib, oracle, scene_id):
+    """cfg/mulran_kaist_dyncfg_laserlike.yaml: ONE ray per azimuth (n_samples 1, beam_width 1e-4 deg, D1), one pass, no
+    smear kernel (signal_denoising 0: the max branch of RadarCPU.cpp:438-446), no noise -- the one-ray-per-azimuth corner of
+    the pass-0 tiling (a wave holds one beam sample of 16 azimuths: here the ONLY sample)."""
+    cfg = params.laserlike_preset()
+    assert (cfg.n_samples, cfg.n_reflections, cfg.signal_denoising, cfg.ambient_noise) == (1, 1, 0, 0)
+    if scene_id == "two_rooms":
+        s = gen.two_room_scene()
+        mats, pose = params.kaist_materials() + [params.PENETRABLE], scenes.default_pose("box12")
+    elif scene_id == "config2":
+        s = scenes.config_scene(2)
+        mats, pose = params.kaist_materials(), scenes.default_pose(s["name"])
+    else:
+        s = scenes.heightfield_room(160, n_buildings=900, seed=3)
+        mats, pose = params.kaist_materials() + [params.PENETRABLE], scenes.default_pose(s["name"])
+    beams = _beam_of(native_lib, cfg)
+    assert beams.shape == (1, 3) and abs(beams[0, 0] - 1.0) < 1e-6            # a 1.7e-6 rad cone: the boresight
+    g8, st = _render_and_compare(native_lib, oracle, s, cfg, mats, s["object_materials"], beams, pose)
+    assert st["wave_passes"] == 400 and st["signals"] == st["hits"] == 400     # closed scenes: every ray returns one echo
+    # one echo per column, unsmeared: ONE non-zero pixel, at energy_max * signal_max = 79 (RadarCPU.cpp:453,533) -- or none
+    # where the echo lies beyond the last bin (3424 x 0.0595 m = 204 m; the 420 m terrain has such azimuths, the rooms none)
+    lit = (g8 > 0).sum(axis=0)
+    assert np.all(lit <= 1) and np.all(g8.max(axis=0)[lit == 1] == 79) and lit.sum() >= (1 if scene_id == "config2" else 100)
+    if scene_id == "two_rooms":
+        assert np.all(lit == 1)
+
+
+def test_preset_minimal_with_its_default_motion_and_noise(native_lib, oracle):
+    """cfg/mulran_kaist_dyncfg_minimal.yaml: 10 samples in a 2 degree beam, W = 23 with mode 0.1 -> int(2.3) = 2, weaker
+    Perlin noise; the file sets neither include_motion nor signal_max, so the .cfg defaults hold: per-azimuth poses
+    (RadarCPU.cpp:190-196) and 120."""
+    cfg = params.minimal_preset()
+    assert cfg.include_motion and cfg.ambient_noise == 2 and cfg.signal_max == 120.0
+    s = scenes.heightfield_room(64, n_buildings=40, seed=3)
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    z = scenes.default_pose(s["name"])[6]
+    sweep = np.stack([scenes.yaw_pose(1.0 + 1.5 * t, 1.5 + 0.5 * t, z, 0.3 + 0.2 * t) for t in np.linspace(0, 1, 400)])
+    noise = (np.random.RandomState(11).uniform(0, 1, 400) * 1000.0).astype(np.float32)
+    g8, st = _render_and_compare(native_lib, oracle, s, cfg, mats, s["object_materials"], _beam_of(native_lib, cfg), sweep, noise)
+    assert st["wave_passes"] >= 4000 and (g8 > 0).mean() > 0.9                 # the noise floor fills the image
+
+
+def test_preset_kaist_at_its_own_50_samples(native_lib, oracle):
+    """cfg/mulran_kaist_dyncfg.yaml as it is (the paper preset): 50 samples, 10 degrees, D3 / p 0.8, 4 passes, W = 35 mode
+    0.35, Perlin noise -- on the 1M-triangle scene of config 3, whole frame."""
+    cfg = params.kaist_preset()
+    assert cfg.n_samples == 50 and cfg.ambient_noise == 2 and not cfg.include_motion
+    s = scenes.config_scene(3)
+    from common import materials_for
+    noise = (np.random.RandomState(7).uniform(0, 1, 400) * 1000.0).astype(np.float32)
+    g8, st = _render_and_compare(native_lib, oracle, s, cfg, materials_for(s), s["object_materials"], _beam_of(native_lib, cfg),
+                                 scenes.default_pose(s["name"]), noise)
+    assert st["wave_passes"] > 400 * 50
+
+
+@pytest.mark.parametrize("fmt", ["dae", "obj"])
+def test_oru4_test_materials_on_an_18_object_scene_through_the_c_loader(native_lib, oracle, tmp_path, fmt):
+    """config/oru4_test.yaml: 5 materials (glass v = 0.03 refracts; wood / metal C = 1; stone C = 3000) mapped onto 18
+    objects by `object_materials`.  The scene (same 18 objects, same order; the reference's .dae is author-local) is written
+    as a map FILE and comes back through rr_load_mesh_file like the node's map does (radar_simulator.cpp:149); KAIST
+    preset, 4 passes."""
+    from radarays_ros_amd import meshio
+    s = scenes.oru4_like_scene()
+    path = str(tmp_path / ("oru4_like." + fmt))
+    if fmt == "dae":
+        meshio.save_dae(path, s["verts"], s["faces"], s["face_object_id"], s["object_names"])
+    else:
+        with open(path, "w") as f:
+            for oid, name in enumerate(s["object_names"]):
+                f.write("o %s-mesh\n" % name)
+                sel = s["faces"][s["face_object_id"] == oid]
+                used = np.unique(sel)
+                for v in s["verts"][used]:
+                    f.write("v %r %r %r\n" % tuple(float(x) for x in v))
+                # negative (relative) indices: the group's own vertices
+                remap = {int(u): k - len(used) for k, u in enumerate(used)}
+                for t in sel:
+                    f.write("f %d %d %d\n" % tuple(remap[int(x)] for x in t))
+    m = native_lib.load_mesh_file(path)
+    # (a .dae geometry is  <geometry id="X-mesh" name="X">: the loader reports the name, oru4_test.yaml's comments the id)
+    assert m["n_objects"] == 18 and [n.replace("-mesh", "") for n in m["object_names"]] == scenes.ORU4_OBJECT_NAMES
+    assert len(m["faces"]) == len(s["faces"]) and np.array_equal(np.bincount(m["face_object_id"]), np.bincount(s["face_object_id"]))
+    mats, objmat = params.oru4_test_materials(), params.ORU4_OBJECT_MATERIALS
+    assert len(objmat) == m["n_objects"]
+    cfg = params.kaist_preset(ambient_noise=0, n_samples=40)
+    pose = scenes.default_pose(s["name"])
+    loaded = {"verts": m["verts"], "faces": m["faces"], "face_object_id": m["face_object_id"]}
+    g8, st = _render_and_compare(native_lib, oracle, loaded, cfg, mats, objmat, golden_beams(40), pose, use_bvh=0)
+    # glass transmits: more waves than reflections alone would give (an opaque scene has <= 400 * 40 * 4)
+    opaque = [params.RadarMaterial(0.0, m_.ambient, m_.diffuse, m_.specular) if i else m_ for i, m_ in enumerate(mats)]
+    c = native_lib.Context(0)
+    c.set_mesh(loaded["verts"], loaded["faces"], loaded["face_object_id"])
+    c.set_materials(opaque, objmat, 0); c.set_config(cfg); c.set_beam_samples(golden_beams(40))
+    o8, _, ost = c.simulate(pose)
+    c.close()
+    assert st["wave_passes"] > ost["wave_passes"] and not np.array_equal(o8, g8)
