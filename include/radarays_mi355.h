@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 4
+#define RR_ABI_VERSION 5
 #define RR_MAX_BATCH 64   /* frames (poses or material sets) one call renders in one set of launches */
 
 typedef struct rr_ctx rr_ctx;
@@ -314,6 +314,14 @@ int rr_debug_trace(rr_ctx* ctx, const float* origs /*[n][3]*/, const float* dirs
 /* BVH facts: nodes, leaf triangle records (>= faces: the host builder may cut a face by spatial splits and keeps
  * one record per part, at most twice the faces), depth, stack entries needed. */
 int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* depth, uint32_t* stack_need);
+/* How the later-pass trace launches are sized (round 5).  A segment holds at most n_beam * 2^pass waves in pass `pass`;
+ * instead of a row of 16-ray workgroups up to that bound per segment, a row is as long as earlier batches of this context
+ * needed (the largest per-segment count seen per pass, + 1/16 + 32 rays), and a segment that exceeds its row anyway is
+ * finished by a small repair launch -- images never depend on the history.  Synchronises the device.
+ *   out_rows[p]  workgroups per segment row of pass p in the last call's launches (0: the doubling bound)
+ *   out_hist[p]  the largest per-segment wave count seen in pass p since mesh / materials / beam / config last changed
+ *   *repaired_groups  16-ray groups the repair launches had to trace since then (0 once the history has settled) */
+int rr_get_trace_grid(rr_ctx* ctx, uint32_t out_rows[24], uint32_t out_hist[24], uint64_t* repaired_groups);
 /* average duration (ms) of the trace kernel launches since the last call with
  * reset!=0, measured with hipEvents on the launch stream when timing mode is
  * on; also returns the number of launches.  Used by bench.py for roofline. */
@@ -414,6 +422,8 @@ void rr_free_mesh(rr_mesh* m);
  * RR_COPY_BLOCKS (8)      one-wave workgroups of a trace launch that trickle a deferred host copy; 0: never fold
  * RR_FOLD_MIN_BUSY (2)    other lanes that must be busy for a host copy to be folded into the next batch
  * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)
+ * RR_TIGHT_GRID (1)       later-pass trace rows sized by the history of earlier batches (rr_get_trace_grid); 0: the doubling bound
+ * RR_TIGHT_FORCE (0)      n > 0: rows of n workgroups whatever the history says (tests: nearly every ray goes through the repair launch)
  * RR_STACK_LDS (64)       traversal stack entries kept in LDS (lower: exercises the HBM spill path)
  * RR_PASS0_AZ (16)        neighbouring azimuths per pass-0 wave (1, 2, 4, 8, 16)
  * RR_ROCTX (0)            1: roctx ranges around the kernel enqueues (rocprofv3 --marker-trace)

@@ -87,6 +87,11 @@ struct Lane {
     std::vector<float4> h_set_beams, h_matsets; std::vector<uint32_t> h_set_order, h_set_order2;
     int last_n_seg = 0, last_n_passes = 0;
     int spill_stride = 0, stack_lds = 1;
+    // tight later-pass trace grids (rr_device.h: GridHint): the lane's history / overflow counters, the overflow lists,
+    // and the page-locked copy of the history that arrives behind every batch (read without a fence: it is a hint)
+    DevBuf<GridHint> d_hint; DevBuf<uint32_t> d_ovf_list; int ovf_stride = 0;
+    uint32_t* h_hist = nullptr; int hist_gen = 0;
+    unsigned short last_rows[kMaxPasses] = {};     // rows the lane's last batch was launched with (0: the bound)
 
     hipStream_t stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_consumed = nullptr;
@@ -172,6 +177,9 @@ struct rr_ctx {
     int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
     int cull_pop = 1;            // k_trace's later passes drop stack entries at pop time (RR_CULL_POP=0: off; the images are the same either way)
     int copy_blocks = 8;         // workgroups (one wave each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
+    int tight_grid = 1;          // later-pass trace rows sized by what earlier batches needed (RR_TIGHT_GRID=0: the doubling bound)
+    int tight_force = 0;         // RR_TIGHT_FORCE=n: rows of n workgroups whatever the history says (tests of the repair path)
+    int hist_gen = 1;            // bumped whenever mesh / materials / beam / config change: the lanes' histories start over
 };
 
 namespace {
@@ -299,6 +307,7 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, hipDeviceSynchronize());   // frames in flight on the lanes still read the old tables
     const rr_config& g = c->cfg;
     const unsigned dirty = c->tables_dirty;
+    if (dirty & (rr_ctx::D_CFG | rr_ctx::D_BEAMS | rr_ctx::D_MAT)) c->hist_gen++;     // wave counts per pass change: the trace-grid history starts over
     if (dirty & rr_ctx::D_CFG) {
     // Tas.R = EulerAngles{0,0,theta(angle)} -> quaternion (rmagine ZYX), RadarCPU.cpp:202
     std::vector<float4> qas((size_t)g.n_angles);
@@ -416,6 +425,9 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     if (!L.d_counters.p) { RR_HIP(c, L.d_counters.ensure(1)); RR_HIP(c, hipMemset(L.d_counters.p, 0, sizeof(Counters))); }
     if (!L.d_sticky.p) { RR_HIP(c, L.d_sticky.ensure(1)); RR_HIP(c, hipMemset(L.d_sticky.p, 0, sizeof(uint32_t))); }
     RR_HIP(c, L.d_seg_stats.ensure(S * (size_t)std::max(1, g.n_reflections)));
+    if (!L.d_hint.p) { RR_HIP(c, L.d_hint.ensure(1)); RR_HIP(c, hipMemset(L.d_hint.p, 0, sizeof(GridHint))); L.hist_gen = 0; }
+    if (!L.h_hist) { RR_HIP(c, hipHostMalloc((void**)&L.h_hist, kMaxPasses * sizeof(uint32_t), hipHostMallocDefault)); std::memset(L.h_hist, 0, kMaxPasses * sizeof(uint32_t)); }
+    RR_HIP(c, L.d_ovf_list.ensure(S * (size_t)kMaxPasses)); L.ovf_stride = (int)S;
     RR_HIP(c, L.d_cols_u8.ensure(S * g.n_cells));
     if (want_f32) RR_HIP(c, L.d_cols_f32.ensure(S * g.n_cells));
     // traversal stack: LDS part + spill
@@ -502,6 +514,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.spill_depth = std::max(0, (int)c->stack_need - L.stack_lds);
     P.pass0_az = c->pass0_az;
     P.cull_pop = c->cull_pop;
+    P.grid_hint = L.d_hint.p; P.ovf_list = L.d_ovf_list.p; P.ovf_stride = L.ovf_stride;     // rows stay at the bound until run_frame tightens them
 }
 
 // a free copy record of the lane (waits for the oldest copy if both are still in flight)
@@ -608,6 +621,27 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[7 * f + k];
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
     L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
+    // later-pass trace rows as long as earlier batches needed (rr_device.h: GridHint).  Not for the statistics build (the
+    // repair launch does not count), the spill path (its columns are laid out for the full rows) or parameter batches
+    // (frames with their own beams and passes)
+    if (L.hist_gen != c->hist_gen) {
+        RR_HIP(c, hipMemsetAsync(L.d_hint.p, 0, sizeof(GridHint), s));
+        std::memset(L.h_hist, 0, kMaxPasses * sizeof(uint32_t));
+        L.hist_gen = c->hist_gen;
+    }
+    const bool tight = c->tight_grid && !c->stats_mode && !P.set_mode && P.spill_depth == 0 && g.n_reflections <= kMaxPasses;
+    if (tight) {
+        for (int pass = 1; pass < g.n_reflections; pass++) {
+            const long bound = std::min<long>((long)P.cap, pass < 20 ? (long)P.n_beam << pass : (long)P.cap);
+            const long full = (bound + 15) / 16;
+            uint32_t h = 0;
+            for (const Lane& o : c->lanes) if (o.h_hist && o.hist_gen == c->hist_gen) h = std::max(h, o.h_hist[pass]);
+            long row = h ? std::min<long>(full, ((long)h + (long)h / 16 + 32 + 15) / 16) : full;
+            if (c->tight_force) row = std::min<long>(full, c->tight_force);
+            P.tight_groups[pass] = (row < full && row < 65535) ? (unsigned short)row : 0;
+        }
+    }
+    std::memcpy(L.last_rows, P.tight_groups, sizeof(L.last_rows));
     for (int pass = 0; pass < g.n_reflections; pass++) {
         // the previous batch's images ride on the later-pass launches, one slice each (rr_simulate_batch_host_async)
         P.copy_blocks = 0;
@@ -631,6 +665,8 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         if (pass < g.n_reflections - 1) { TimedScope t(c, s, "scan"); launch_scan(P, pass, s); }
     }
     { TimedScope t(c, s, "column"); launch_column(P, s); }
+    // the history this batch leaves behind travels to the host behind it (96 B; read without a fence by later batches)
+    if (c->tight_grid && g.n_reflections > 1) RR_HIP(c, hipMemcpyAsync(L.h_hist, L.d_hint.p->hist, kMaxPasses * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RR_HIP(c, hipGetLastError());
     return 0;
 }
@@ -703,6 +739,8 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
     if (getenv("RR_CULL_POP")) c->cull_pop = atoi(getenv("RR_CULL_POP")) != 0;
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
+    if (getenv("RR_TIGHT_GRID")) c->tight_grid = atoi(getenv("RR_TIGHT_GRID")) != 0;
+    if (getenv("RR_TIGHT_FORCE")) c->tight_force = std::max(0, atoi(getenv("RR_TIGHT_FORCE")));
     {   // the one angle of total reflection that does not depend on the material table
         const float4 same = make_float4(0.3f, 0.f, 0.f, 0.f);
         DevBuf<float4> m1; DevBuf<double> l1;
@@ -740,6 +778,7 @@ void rr_destroy(rr_ctx* c)
         L.d_refpos.release();
         L.d_hit.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
         L.d_sigtmp.release(); L.d_sig.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_matset_limits.release(); L.d_set_beams.release(); L.d_set_order.release(); L.d_set_order2.release(); L.d_img_u8.release(); L.d_img_f32.release();
+        L.d_hint.release(); L.d_ovf_list.release(); if (L.h_hist) { (void)hipHostFree(L.h_hist); L.h_hist = nullptr; }
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         for (Lane::CopyRec& r : L.rec) if (r.ev) (void)hipEventDestroy(r.ev);
@@ -772,7 +811,7 @@ int upload_tree(rr_ctx* c, const Bvh4& bvh)
     RR_HIP(c, hipDeviceSynchronize());
     c->n_nodes = nn; c->n_tris = nt;
     c->depth = bvh.depth; c->stack_need = bvh.stack_need;
-    c->have_mesh = true;
+    c->have_mesh = true; c->hist_gen++;
     for (Lane& L : c->lanes) L.buf_seg = 0;   // stack geometry may have changed
     return 0;
 }
@@ -1643,6 +1682,26 @@ int rr_reserve_timing_events(rr_ctx* c, size_t n)
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
     while (c->event_pool.size() < n) { hipEvent_t e = nullptr; RR_HIP(c, hipEventCreate(&e)); c->event_pool.push_back(e); }
+    return 0;
+}
+
+int rr_get_trace_grid(rr_ctx* c, uint32_t out_rows[24], uint32_t out_hist[24], uint64_t* repaired_groups)
+{
+    if (!c) return -1;
+    static_assert(kMaxPasses == 24, "rr_get_trace_grid's arrays");
+    RR_HIP(c, hipSetDevice(c->device));
+    RR_HIP(c, hipDeviceSynchronize());
+    const Lane& L = c->lanes[c->last_lane];
+    uint64_t rep = 0;
+    for (int k = 0; k < kMaxPasses; k++) { if (out_rows) out_rows[k] = L.last_rows[k]; if (out_hist) out_hist[k] = 0; }
+    for (const Lane& o : c->lanes) {
+        if (!o.d_hint.p || o.hist_gen != c->hist_gen) continue;
+        GridHint h;
+        RR_HIP(c, hipMemcpy(&h, o.d_hint.p, sizeof(h), hipMemcpyDeviceToHost));
+        rep += h.repaired;
+        for (int k = 0; k < kMaxPasses && out_hist; k++) out_hist[k] = std::max(out_hist[k], h.hist[k]);
+    }
+    if (repaired_groups) *repaired_groups = rep;
     return 0;
 }
 

@@ -82,6 +82,17 @@ struct Counters {
     unsigned long long it_all, it_node, it_leaf, quad_steps;   // stats mode: wave-loop iterations (all / issuing the node path / the leaf path), quad steps
 };
 
+// Tight later-pass trace grids (round 5).  A segment holds at most n_beam * 2^pass waves in pass `pass`, and launch_trace
+// used to launch a row of 16-ray workgroups up to that bound per segment; far fewer are live (10M-triangle target, pass 3:
+// 62 of 100), and a workgroup that starts only to read its segment's count and leave costs a dispatch and a wave slot.
+// The host now sizes the row by what earlier batches needed: hist[p] = the largest count any segment had in pass p
+// (monotone maximum, written by k_scan; copied to the host behind every batch), rows of hist * 17/16 + 32 rays.  A segment
+// that exceeds its row anyway is put on ovf_list by k_scan and its remaining groups are traced by k_trace_repair, a small
+// launch that follows every tightened trace launch and exits at once when the list is empty: results never depend on
+// the hint.
+constexpr int kMaxPasses = 24;
+struct GridHint { uint32_t hist[kMaxPasses]; uint32_t ovf_n[kMaxPasses]; unsigned long long repaired; /* 16-ray groups k_trace_repair traced since the history started over */ };
+
 // per (pass, azimuth) counters, written once by the kernel that finishes the pass
 // (no atomics in the frame path: ~10 ns each, they serialise at the L2)
 struct SegStats { uint32_t wave_passes, hits, signals, pad; };
@@ -157,6 +168,11 @@ struct Params {
     // device memory to page-locked host memory, one 1-KB store per wave in flight
     const uint4* copy_src; uint4* copy_dst; unsigned long long copy_n16; int copy_blocks;
     int cull_pop;            // later passes / rr_debug_trace: drop stack entries at pop time by their 16-bit distance bound (0: off, RR_CULL_POP=0)
+    // tight later-pass trace grids (GridHint above)
+    GridHint* grid_hint;     // per lane; null: off
+    uint32_t* ovf_list;      // [n_passes][ovf_stride] segments whose count exceeds the tightened row of that pass
+    int ovf_stride;
+    unsigned short tight_groups[kMaxPasses];   // 16-ray workgroups per segment row of pass p; 0: the full doubling bound
 };
 
 __host__ __device__ inline int passes_of(const Params& P, int frame) { return P.set_mode ? (int)P.frame_passes[frame] : P.n_passes; }

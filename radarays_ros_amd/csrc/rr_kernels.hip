@@ -238,47 +238,17 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
     return best;
 }
 
-// grid: (ceil(bound/16) [+ a copy row], n_seg), block 64 (= one wave = 16 rays), dynamic LDS = stack_lds * 16 * (4 | 6) B
+// one 16-ray group (= one wave) of a trace launch: group gx of segment row seg_y (pass 0: tile gx of the flat sequence)
 template <bool FIRST, bool STATS, bool SPILL, bool CULL>
-__global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
+__device__ __forceinline__ void trace_group(const Params& P, const int pass, const int seg_y, const int gx, const int count,
+                                            uint32_t* lds_stack, const int gdim_x)
 {
-    // k_trace is the long pole of a step: its waves go first when they share a SIMD with the
-    // column / shade waves of the other steps in flight (config 2: live launch 135 -> 122 us)
-    __builtin_amdgcn_s_setprio(2);
-    extern __shared__ uint32_t lds_stack[];
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int cur = pass & 1;
-    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
-    // pass 0: the rays of ALL segments of the launch are tiled into waves of (16 / A) beam samples x A
-    // neighbouring azimuths (A = pass0_az = 16: ONE sample in 16 azimuths, i.e. 16 rays of identical
-    // elevation, 0.9 degrees apart, that walk almost the same nodes in lockstep -- few iterations pay both
-    // the node and the leaf path, no slow ray to wait for), and the tiles are launched sample-block-major,
-    // so the waves that run at the same time are neighbours in azimuth: k_trace 128 us (round 1: Morton
-    // order of the samples inside one azimuth, azimuth after azimuth) -> 80 us per 640k rays at config 2.
-    // Every wave is full, too (200 rays per azimuth would otherwise leave a 13th wave with 8 rays)
-    // later passes may carry a host copy in row 0 of the grid (see Params::copy_src)
-    const int row0 = FIRST ? 0 : (P.copy_blocks > 0 ? 1 : 0);
-    if (!FIRST && row0 && blockIdx.y == 0) {
-        if ((int)blockIdx.x < P.copy_blocks) {
-            __builtin_amdgcn_s_setprio(0);
-            const size_t nthreads = (size_t)P.copy_blocks * kTraceThreads;
-            for (size_t i = (size_t)blockIdx.x * kTraceThreads + threadIdx.x; i < P.copy_n16; i += nthreads) {
-                const uint4 v = P.copy_src[i];
-                P.copy_dst[i] = v;
-                // ONE store per wave in flight: the writes leave at the pace PCIe takes them instead of filling the
-                // memory pipeline's write queues, where the stores of every other kernel would wait behind them
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        return;
-    }
-    const int seg_y = (int)blockIdx.y - row0;
-    const int count = FIRST ? 0 : (int)P.count[cur][seg_y];
-    if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
     RaySetup R; int j, seg;
     {
         const int rr = r;          // every lane of the quad prepares its ray itself: the same instructions as one lane per ray and an LDS hand-off (round 2), without the hand-off and its two barriers
-        int k = blockIdx.x * kRaysPerBlock + rr;           // trace slot
+        int k = gx * kRaysPerBlock + rr;           // trace slot
         seg = seg_y;
         bool live = k < count;
         if (FIRST) {
@@ -286,7 +256,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
             const int ns = P.set_mode ? P.n_groups * P.n_loc : P.n_seg;     // parameter sets: one pass 0 per beam group
             const int A = P.pass0_az, lgA = 31 - __builtin_clz(A), Sw = kRaysPerWave >> lgA;
             const int n_ab = (ns + A - 1) >> lgA;
-            const int w = blockIdx.x * (kRaysPerBlock / kRaysPerWave) + (rr >> 4), r16 = rr & 15;
+            const int w = gx * (kRaysPerBlock / kRaysPerWave) + (rr >> 4), r16 = rr & 15;
             const int sb = w / n_ab, ab = w - sb * n_ab;
             k = sb * Sw + (r16 >> lgA); seg = (ab << lgA) + (r16 & (A - 1));
             live = k < P.n_beam && seg < ns;
@@ -323,7 +293,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     unsigned nn = 0, nt = 0;
     unsigned ws[4] = { 0, 0, 0, 0 };
     if (active) {
-        const int gray = ((FIRST ? 0 : seg_y) * (int)gridDim.x + (int)blockIdx.x) * kRaysPerBlock + r;   // spill column of this ray slot
+        const int gray = ((FIRST ? 0 : seg_y) * gdim_x + (int)gx) * kRaysPerBlock + r;   // spill column of this ray slot
         const Hit h = traverse<STATS, SPILL, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
@@ -352,6 +322,70 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
             atomicAdd(&P.counters->it_node, (unsigned long long)b);
             atomicAdd(&P.counters->it_leaf, (unsigned long long)c2);
             atomicAdd(&P.counters->quad_steps, (unsigned long long)d2);
+        }
+    }
+}
+
+// grid: (ceil(bound/16) [+ a copy row], n_seg), block 64 (= one wave = 16 rays), dynamic LDS = stack_lds * 16 * (4 | 6) B
+template <bool FIRST, bool STATS, bool SPILL, bool CULL>
+__global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
+{
+    // k_trace is the long pole of a step: its waves go first when they share a SIMD with the
+    // column / shade waves of the other steps in flight (config 2: live launch 135 -> 122 us)
+    __builtin_amdgcn_s_setprio(2);
+    extern __shared__ uint32_t lds_stack[];
+    const int cur = pass & 1;
+    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
+        if (P.grid_hint && threadIdx.x < kMaxPasses) P.grid_hint->ovf_n[threadIdx.x] = 0;   // overflow lists of the tightened rows
+    }
+    // pass 0: the rays of ALL segments of the launch are tiled into waves of (16 / A) beam samples x A
+    // neighbouring azimuths (A = pass0_az = 16: ONE sample in 16 azimuths, i.e. 16 rays of identical
+    // elevation, 0.9 degrees apart, that walk almost the same nodes in lockstep -- few iterations pay both
+    // the node and the leaf path, no slow ray to wait for), and the tiles are launched sample-block-major,
+    // so the waves that run at the same time are neighbours in azimuth: k_trace 128 us (round 1: Morton
+    // order of the samples inside one azimuth, azimuth after azimuth) -> 80 us per 640k rays at config 2.
+    // Every wave is full, too (200 rays per azimuth would otherwise leave a 13th wave with 8 rays)
+    // later passes may carry a host copy in row 0 of the grid (see Params::copy_src)
+    const int row0 = FIRST ? 0 : (P.copy_blocks > 0 ? 1 : 0);
+    if (!FIRST && row0 && blockIdx.y == 0) {
+        if ((int)blockIdx.x < P.copy_blocks) {
+            __builtin_amdgcn_s_setprio(0);
+            const size_t nthreads = (size_t)P.copy_blocks * kTraceThreads;
+            for (size_t i = (size_t)blockIdx.x * kTraceThreads + threadIdx.x; i < P.copy_n16; i += nthreads) {
+                const uint4 v = P.copy_src[i];
+                P.copy_dst[i] = v;
+                // ONE store per wave in flight: the writes leave at the pace PCIe takes them instead of filling the
+                // memory pipeline's write queues, where the stores of every other kernel would wait behind them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        return;
+    }
+    const int seg_y = (int)blockIdx.y - row0;
+    const int count = FIRST ? 0 : (int)P.count[cur][seg_y];
+    if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
+    trace_group<FIRST, STATS, SPILL, CULL>(P, pass, seg_y, (int)blockIdx.x, count, lds_stack, (int)gridDim.x);
+}
+
+// The remainder of the segments whose count exceeds the tightened row of this pass (GridHint, rr_device.h): launched
+// behind every tightened k_trace launch with a small fixed grid; every workgroup exits at once when the list is empty.
+// Off the fast path on purpose: the loops here are what the main kernel must not contain (a loop around the ray set-up
+// makes the compiler hoist the kernel-argument loads: 36 -> 94-102 SGPRs, 53 -> 58 VGPRs, +5 % per launch, round 4)
+template <bool CULL>
+__global__ __launch_bounds__(kTraceThreads) void k_trace_repair(const Params P, const int pass)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t n = P.grid_hint->ovf_n[pass];
+    if (n == 0) return;
+    __builtin_amdgcn_s_setprio(2);
+    const int tight = (int)P.tight_groups[pass];
+    for (uint32_t i = 0; i < n; i++) {
+        const int seg = (int)P.ovf_list[(size_t)pass * P.ovf_stride + i];
+        const int count = (int)P.count[pass & 1][seg];
+        for (int g = tight + (int)blockIdx.x; g * kRaysPerBlock < count; g += (int)gridDim.x) {
+            trace_group<false, false, false, CULL>(P, pass, seg, g, count, lds_stack, 0);
+            if (threadIdx.x == 0) atomicAdd(&P.grid_hint->repaired, 1ull);
         }
     }
 }
@@ -770,6 +804,16 @@ __global__ __launch_bounds__(256) void k_scan(const Params P, const int pass)
     if (__syncthreads_or((int)ovf) && threadIdx.x == 0) { atomicOr(&P.counters->overflow, 1u); atomicOr(P.sticky, 1u); }
     if (threadIdx.x == 0) {
         P.count[nxt][seg] = (uint32_t)min(n_child, P.cap);
+        if (P.grid_hint && pass + 1 < kMaxPasses) {     // tight trace grids (rr_device.h: GridHint)
+            const uint32_t cn = (uint32_t)min(n_child, P.cap);
+            // a monotone maximum: once it has settled nobody issues the atomic any more (a stale read only costs one)
+            if (cn > P.grid_hint->hist[pass + 1]) atomicMax(&P.grid_hint->hist[pass + 1], cn);
+            const uint32_t tg = P.tight_groups[pass + 1];
+            if (tg && cn > tg * (uint32_t)kRaysPerBlock) {
+                const uint32_t at = atomicAdd(&P.grid_hint->ovf_n[pass + 1], 1u);
+                P.ovf_list[(size_t)(pass + 1) * P.ovf_stride + at] = (uint32_t)seg;
+            }
+        }
         P.sig_count[seg] = (uint32_t)min(n_sig, P.sigcap);
         SegStats st; st.wave_passes = (uint32_t)count; st.hits = (uint32_t)n_hit;
         st.signals = (uint32_t)(n_sig - sig_before); st.pad = 0;
@@ -1326,8 +1370,11 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     // launched beyond that bound (pass 1 of the KAIST preset: 13 instead of 50 blocks per segment; the rest would
     // read their segment's count and exit)
     const long bound = std::min<long>((long)P.cap, pass < 20 ? (long)P.n_beam << pass : (long)P.cap);
+    // ... and since round 5 the row is as long as earlier batches needed (GridHint): tight_groups[pass], 0 = the bound
+    const unsigned row = (pass > 0 && pass < kMaxPasses && P.tight_groups[pass]) ? (unsigned)P.tight_groups[pass]
+                                                                               : (unsigned)((bound + kRaysPerBlock - 1) / kRaysPerBlock);
     dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + (kTraceThreads / 64) - 1) / (kTraceThreads / 64)))
-                          : dim3((unsigned)((bound + kRaysPerBlock - 1) / kRaysPerBlock), n_seg + (P.copy_blocks > 0 ? 1 : 0));
+                          : dim3(row, n_seg + (P.copy_blocks > 0 ? 1 : 0));
     Params Pl = P;
     if (pass == 0) Pl.copy_blocks = 0;
     else Pl.copy_blocks = std::min<int>(P.copy_blocks, (int)grid.x);      // the copy's workgroups are the first of row 0
@@ -1352,6 +1399,11 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
         else       { if (spill) RR_LAUNCH_TRACE(false, false, true, false); else RR_LAUNCH_TRACE(false, false, false, false); }
     }
 #undef RR_LAUNCH_TRACE
+    if (pass > 0 && pass < kMaxPasses && P.tight_groups[pass]) {     // host guarantees: no statistics build, no spill path
+        const dim3 rgrid(128);
+        if (cull) hipLaunchKernelGGL((k_trace_repair<true>), rgrid, block, lds, s, Pl, pass);
+        else      hipLaunchKernelGGL((k_trace_repair<false>), rgrid, block, lds, s, Pl, pass);
+    }
 }
 
 void launch_shade(const Params& P, int pass, hipStream_t s)

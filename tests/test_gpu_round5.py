@@ -267,3 +267,72 @@ def test_oru4_test_materials_on_an_18_object_scene_through_the_c_loader(native_l
     o8, _, ost = c.simulate(pose)
     c.close()
     assert st["wave_passes"] > ost["wave_passes"] and not np.array_equal(o8, g8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tight later-pass trace rows (rr_get_trace_grid): images never depend on the history
+# ---------------------------------------------------------------------------------------------------------------------
+def _batch(c, poses, cfg):
+    import torch
+    imgs = torch.zeros((len(poses), cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    c.simulate_batch_device(poses, imgs.data_ptr(), st)
+    c.synchronize(st)
+    return imgs.cpu().numpy()
+
+
+def test_tight_trace_rows_follow_the_history_and_never_change_an_image(native_lib, monkeypatch):
+    """Later-pass k_trace launches are as wide as earlier batches needed.  (1) the first batch after a change runs at the
+    doubling bound, later ones tighter, same bytes as with RR_TIGHT_GRID=0; (2) a pose whose segments need MORE than the
+    history (sensor moved between the buildings: more transmitted waves) overflows the tightened rows: the repair launch
+    traces the rest (repaired > 0), same bytes; afterwards the history has grown and nothing is repaired any more;
+    (3) RR_TIGHT_FORCE=1: one workgroup per row, nearly every ray through the repair path, same bytes."""
+    s = scenes.heightfield_room(96, n_buildings=260, seed=3)
+    from common import materials_for
+    cfg = params.kaist_preset(n_reflections=4, n_samples=64, ambient_noise=0)
+    z = scenes.default_pose(s["name"])[6]
+    calm = [scenes.yaw_pose(1.0 + 0.2 * k, 1.5, z + 14.0, 0.3) for k in range(4)]          # high above the roofs: terrain hits, few children
+    busy = [scenes.yaw_pose(60.0 + 3.0 * k, -40.0, z + 1.0, 0.3 + k) for k in range(4)]    # street level between buildings
+
+    def ctx():
+        c = native_lib.Context(0)
+        c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+        c.set_materials(materials_for(s), s["object_materials"], 0)
+        c.set_config(cfg)
+        c.set_beam_samples(golden_beams(64))
+        return c
+    monkeypatch.delenv("RR_TIGHT_FORCE", raising=False)                    # (the suite may run under it)
+    monkeypatch.setenv("RR_TIGHT_GRID", "0")
+    c0 = ctx()
+    want_calm, want_busy = _batch(c0, calm, cfg), _batch(c0, busy, cfg)
+    assert not c0.trace_grid()[0].any()
+    c0.close()
+    monkeypatch.delenv("RR_TIGHT_GRID")
+    c = ctx()
+    assert np.array_equal(_batch(c, calm, cfg), want_calm)
+    rows, hist, rep = c.trace_grid()
+    assert not rows.any() and rep == 0 and hist[1] > 0                     # first batch: no history yet, full rows
+    assert np.array_equal(_batch(c, calm, cfg), want_calm)
+    rows, hist, rep = c.trace_grid()
+    full = [(min(64 << p, 64 << 3) + 15) // 16 for p in range(4)]
+    assert rep == 0 and any(0 < rows[p] < full[p] for p in (2, 3)), (rows[:4], hist[:4])
+    calm_hist = hist.copy()
+    assert np.array_equal(_batch(c, busy, cfg), want_busy)                 # needs more than the calm poses taught
+    rows2, hist2, rep2 = c.trace_grid()
+    assert rep2 > 0 and (hist2[:4] >= calm_hist[:4]).all() and (hist2[:4] > calm_hist[:4]).any(), (rows2[:4], hist2[:4], rep2)
+    assert np.array_equal(_batch(c, busy, cfg), want_busy)
+    assert c.trace_grid()[2] == rep2                                       # the history has grown: nothing left to repair
+    assert np.array_equal(_batch(c, calm, cfg), want_calm)
+    # a change of the beam starts the history over
+    c.set_beam_samples(golden_beams(48))
+    _batch(c, calm, cfg)
+    assert not c.trace_grid()[0].any() and c.trace_grid()[2] == 0
+    c.close()
+    monkeypatch.setenv("RR_TIGHT_FORCE", "1")
+    c1 = ctx()
+    assert np.array_equal(_batch(c1, busy, cfg), want_busy) and np.array_equal(_batch(c1, calm, cfg), want_calm)
+    rows, _, rep = c1.trace_grid()
+    assert rows[2] == 1 and rows[3] == 1 and rep > 1000
+    g8, _, st = c1.simulate(busy[0])                                       # the synchronous entry point takes the same route
+    assert np.array_equal(g8, want_busy[0]) and st["overflow"] == 0
+    c1.close()
