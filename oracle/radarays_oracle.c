@@ -457,11 +457,20 @@ struct orc_scene {
     bvh_node* nodes; size_t n_nodes;
     uint32_t* prim;              /* face indices in leaf order */
     float inflate;
+    float* graze2;               /* per face: 2.5e-5 |e1 x e2|^2 (grazing guard of tri_hit) */
+    float guard_pad;             /* 1e-5 x max(extent, largest |coordinate|) of the mesh */
 };
 
 #define ORC_TFAR 1000.0f   /* make_model range.max, radar_algorithms.cpp:157-158 */
 
-/* Moeller-Trumbore, f32, no FMA.  Accepts 0 < t <= tfar. */
+/* Moeller-Trumbore, f32, no FMA.  Accepts 0 < t <= tfar.
+ * Grazing guard (round 5; the BUILD'S definition -- rmagine / Embree are not in the checkout, their hit selection at
+ * grazing incidence is unknown): for a ray within 0.3 degrees of the triangle's plane (det^2 < 2.5e-5 |e1 x e2|^2, i.e.
+ * |d . n| < 5e-3) the test above is ill-conditioned and may accept a point centimetres outside the triangle -- a point
+ * no bounding hierarchy over the triangle's box would ever visit, so the brute-force loop and a BVH (this file's own
+ * intersect_bvh included) disagreed on such rays (1 in 39M fuzz rays, round 4).  Such a hit counts only if its point
+ * o + t d lies inside the triangle's bounding box padded by guard_pad: the nearest hit is then a property of the mesh, not of
+ * the structure that finds it.  Same arithmetic, un-fused, in the HIP kernel (traverse, rr_kernels.hip). */
 static inline int tri_hit(const struct orc_scene* s, uint32_t f, v3 o, v3 d, float* t_out)
 {
     const v3 e1 = s->e1[f], e2 = s->e2[f];
@@ -477,6 +486,16 @@ static inline int tri_hit(const struct orc_scene* s, uint32_t f, v3 o, v3 d, flo
     if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
     const float t = v3_dot(e2, qvec) * inv;
     if (!(t > 0.0f && t <= ORC_TFAR)) return 0;
+    if (det * det < s->graze2[f]) {
+        const v3 v0 = s->v0[f];
+        const v3 ph = v3_add(o, v3_scale(d, t)), v1 = v3_add(v0, e1), v2 = v3_add(v0, e2);
+        const float pad = s->guard_pad;
+        const int inside =
+            ph.x >= fminf(v0.x, fminf(v1.x, v2.x)) - pad && ph.x <= fmaxf(v0.x, fmaxf(v1.x, v2.x)) + pad &&
+            ph.y >= fminf(v0.y, fminf(v1.y, v2.y)) - pad && ph.y <= fmaxf(v0.y, fmaxf(v1.y, v2.y)) + pad &&
+            ph.z >= fminf(v0.z, fminf(v1.z, v2.z)) - pad && ph.z <= fmaxf(v0.z, fmaxf(v1.z, v2.z)) + pad;
+        if (!inside) return 0;
+    }
     *t_out = t;
     return 1;
 }
@@ -642,6 +661,7 @@ orc_scene* orc_scene_create(const float* verts, size_t nv, const uint32_t* faces
     s->e1 = (v3*)malloc(sizeof(v3) * (nf ? nf : 1));
     s->e2 = (v3*)malloc(sizeof(v3) * (nf ? nf : 1));
     s->obj = (uint32_t*)malloc(sizeof(uint32_t) * (nf ? nf : 1));
+    s->graze2 = (float*)malloc(sizeof(float) * (nf ? nf : 1));
     float smin[3] = { INFINITY, INFINITY, INFINITY }, smax[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (size_t f = 0; f < nf; f++) {
         const float* a = verts + 3 * (size_t)faces[3 * f + 0];
@@ -649,6 +669,7 @@ orc_scene* orc_scene_create(const float* verts, size_t nv, const uint32_t* faces
         const float* c = verts + 3 * (size_t)faces[3 * f + 2];
         v3 va = { a[0], a[1], a[2] }, vb = { b[0], b[1], b[2] }, vc = { c[0], c[1], c[2] };
         s->v0[f] = va; s->e1[f] = v3_sub(vb, va); s->e2[f] = v3_sub(vc, va);
+        { const v3 cr = v3_cross(s->e1[f], s->e2[f]); s->graze2[f] = 2.5e-5f * v3_dot(cr, cr); }
         s->obj[f] = face_object_id ? face_object_id[f] : 0u;
         for (int k = 0; k < 3; k++) {
             float lo = fminf(a[k], fminf(b[k], c[k])), hi = fmaxf(a[k], fmaxf(b[k], c[k]));
@@ -658,6 +679,13 @@ orc_scene* orc_scene_create(const float* verts, size_t nv, const uint32_t* faces
     }
     (void)nv;
     s->use_bvh = use_bvh < 0 ? (nf > 4096) : use_bvh;
+    s->guard_pad = 0.0f;
+    if (nf > 0) {
+        float ext = fmaxf(smax[0] - smin[0], fmaxf(smax[1] - smin[1], smax[2] - smin[2]));
+        float mag = 0.0f;
+        for (int k = 0; k < 3; k++) mag = fmaxf(mag, fmaxf(fabsf(smin[k]), fabsf(smax[k])));
+        s->guard_pad = 1e-5f * fmaxf(ext, mag);
+    }
     if (s->use_bvh && nf > 0) {
         float ext = fmaxf(smax[0] - smin[0], fmaxf(smax[1] - smin[1], smax[2] - smin[2]));
         float mag = 0.0f;
@@ -689,7 +717,7 @@ orc_scene* orc_scene_create(const float* verts, size_t nv, const uint32_t* faces
 void orc_scene_destroy(orc_scene* s)
 {
     if (!s) return;
-    free(s->v0); free(s->e1); free(s->e2); free(s->obj); free(s->nodes); free(s->prim);
+    free(s->v0); free(s->e1); free(s->e2); free(s->obj); free(s->graze2); free(s->nodes); free(s->prim);
     free(s);
 }
 

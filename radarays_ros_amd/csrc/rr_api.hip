@@ -29,7 +29,7 @@ bool build_bvh4_gpu(const float* verts, size_t nv, const uint32_t* faces, size_t
                     std::string& err, hipStream_t stream);
 void launch_debug_trace(const Params& P, const float* origs, const float* dirs, int n,
                         float* out_t, uint32_t* out_face, hipStream_t s, unsigned long long* steps = nullptr);
-void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s);
+void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s, size_t n_tris);
 void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
 }  // namespace rr
@@ -121,6 +121,7 @@ struct rr_ctx {
     uint32_t tri_base4 = 0;        // float4 offset of triangle 0
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t depth = 0, stack_need = 0;
+    float hit_pad = 0.f;           // grazing guard of the triangle test (traverse): 1e-5 x the extent of the faces' vertices = half the builders' box padding
 
     // params
     rr_config cfg;
@@ -504,7 +505,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.signal_denoising = c->smear.empty() ? 0 : g.signal_denoising;
     P.smear_w = (int)c->smear.size(); P.smear_mode = c->smear_mode;
     P.ambient_noise = g.ambient_noise; P.scroll = g.scroll_image;
-    P.thr = g.wave_energy_threshold; P.range_max = g.range_max;
+    P.thr = g.wave_energy_threshold; P.range_max = g.range_max; P.hit_pad = c->hit_pad;
     P.resolution = g.resolution; P.multipath_threshold = g.multipath_threshold;
     P.energy_max_f = (float)g.energy_max; P.signal_max = g.signal_max;
     P.noise_at_0 = g.ambient_noise_at_signal_0; P.noise_at_1 = g.ambient_noise_at_signal_1;
@@ -793,6 +794,22 @@ const char* rr_last_error(const rr_ctx* c) { return c ? c->err.c_str() : g_creat
 
 namespace {
 
+// The grazing guard's padding (traverse, rr_kernels.hip): 1e-5 x max(extent, largest |coordinate|) of the vertices the faces
+// use -- half of what both builders pad their boxes with (2e-5 x the same measure + 1e-6; the GPU builder measures ALL
+// vertices, which can only give more).  One multiplication: nothing a compiler could contract; the oracle forms the same value
+float guard_pad(const float* verts, const uint32_t* faces, size_t nf)
+{
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = 0; i < 3 * nf; i++) {
+        const float* v = verts + 3 * (size_t)faces[i];
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); }
+    }
+    if (nf == 0) return 0.f;
+    float ext = 0.f, mag = 0.f;
+    for (int k = 0; k < 3; k++) { ext = std::max(ext, hi[k] - lo[k]); mag = std::max(mag, std::max(std::fabs(lo[k]), std::fabs(hi[k]))); }
+    return 1e-5f * std::max(ext, mag);
+}
+
 // the finished host tree -> the ctx's one allocation (nodes, then triangles; references re-encoded as offsets)
 int upload_tree(rr_ctx* c, const Bvh4& bvh)
 {
@@ -806,7 +823,7 @@ int upload_tree(rr_ctx* c, const Bvh4& bvh)
     RR_HIP(c, c->d_bvh.ensure(nn * 8 + (nt + 4) * 3));   // +4 triangles: a quad may fetch past a short leaf
     RR_HIP(c, hipMemcpy(c->d_bvh.p, bvh.nodes.data(), nn * sizeof(Node4), hipMemcpyHostToDevice));
     if (nt) RR_HIP(c, hipMemcpy(c->d_bvh.p + c->tri_base4, bvh.tris.data(), nt * sizeof(TriRec), hipMemcpyHostToDevice));
-    launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr);
+    launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr, nt);
     RR_HIP(c, hipGetLastError());
     RR_HIP(c, hipDeviceSynchronize());
     c->n_nodes = nn; c->n_tris = nt;
@@ -845,7 +862,7 @@ int measure_tree_steps(rr_ctx* c, const float lo[3], const float hi[3], double* 
     if (e == hipSuccess) {
         Params P; std::memset(&P, 0, sizeof(P));
         P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
-        P.tri_base4 = c->tri_base4; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
+        P.tri_base4 = c->tri_base4; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f; P.hit_pad = c->hit_pad;
         P.spill = d_spill.p; P.spill_stride = n; P.stack_lds = stack_lds; P.spill_depth = std::max(0, spill_depth);
         P.cull_pop = c->cull_pop;
         launch_debug_trace(P, d_o.p, d_d.p, n, nullptr, nullptr, c->stream, d_steps.p);
@@ -885,6 +902,7 @@ int rr_set_mesh(rr_ctx* c, const float* verts, size_t nv, const uint32_t* faces,
     // frames in flight on the lane streams or a caller's stream (all non-blocking: a blocking hipMemcpy
     // does not order against them) still trace the old tree
     RR_HIP(c, hipDeviceSynchronize());
+    c->hit_pad = guard_pad(verts, faces, nf);       // (build_bvh4 has checked the indices)
     int rc = upload_tree(c, bvh); if (rc) return rc;
     if (choose) {
         float lo[3] = { 3e38f, 3e38f, 3e38f }, hi[3] = { -3e38f, -3e38f, -3e38f };
@@ -939,12 +957,13 @@ int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* fa
         (void)hipFree(dn); (void)hipFree(dt);
         if (rc) return rc;
         RR_HIP(c, e);
-        launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr);
+        launch_encode_refs(reinterpret_cast<Node4*>(c->d_bvh.p), nn, c->tri_base4, nullptr, nt);
         RR_HIP(c, hipGetLastError());
         RR_HIP(c, hipDeviceSynchronize());
     }
     c->n_nodes = nn; c->n_tris = nt; c->depth = depth; c->stack_need = need;
-    c->have_mesh = true;
+    c->hit_pad = guard_pad(verts, faces, nf);
+    c->have_mesh = true; c->hist_gen++;
     for (Lane& L : c->lanes) L.buf_seg = 0;
     return 0;
 }
@@ -968,8 +987,8 @@ int rr_copy_mesh(rr_ctx* c, rr_ctx* src)
     else RR_HIP(c, hipMemcpyPeer(c->d_bvh.p, c->device, src->d_bvh.p, src->device, n4 * sizeof(float4)));
     RR_HIP(c, hipDeviceSynchronize());
     c->tri_base4 = src->tri_base4; c->n_nodes = src->n_nodes; c->n_tris = src->n_tris;
-    c->depth = src->depth; c->stack_need = src->stack_need;
-    c->have_mesh = true;
+    c->depth = src->depth; c->stack_need = src->stack_need; c->hit_pad = src->hit_pad;
+    c->have_mesh = true; c->hist_gen++;
     return 0;
 }
 
@@ -1731,7 +1750,7 @@ int rr_debug_trace(rr_ctx* c, const float* origs, const float* dirs, size_t n, f
     RR_HIP(c, d_f.ensure(chunk)); RR_HIP(c, d_spill.ensure(spill_depth > 0 ? (size_t)spill_depth * chunk : 1));
     Params P; std::memset(&P, 0, sizeof(P));
     P.nodes = reinterpret_cast<const Node4*>(c->d_bvh.p); P.tris = reinterpret_cast<const TriRec*>(c->d_bvh.p + c->tri_base4);
-    P.tri_base4 = c->tri_base4; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f;
+    P.tri_base4 = c->tri_base4; P.range_max = c->have_cfg ? c->cfg.range_max : 1000.0f; P.hit_pad = c->hit_pad;
     P.spill = d_spill.p; P.spill_stride = (int)chunk; P.stack_lds = stack_lds; P.spill_depth = std::max(0, spill_depth);
     P.cull_pop = c->cull_pop;
     int rc = 0;

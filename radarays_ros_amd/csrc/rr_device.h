@@ -157,6 +157,7 @@ struct Params {
     int brdf_model;              // 0: A + B cos^C (reference); 1: Cook-Torrance lobe (build's own, rr_config.brdf_model)
     int signal_denoising, smear_w, smear_mode, ambient_noise, scroll;
     float thr, range_max;
+    float hit_pad;               // grazing guard of the triangle test: half the builders' box padding (traverse, rr_kernels.hip)
     double resolution, multipath_threshold;
     float energy_max_f;          // (float)energy_max  (cv convertTo alpha)
     double signal_max;

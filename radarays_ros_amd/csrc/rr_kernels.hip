@@ -99,7 +99,7 @@ __device__ inline RaySetup ray_setup(V3 o, V3 d)
 
 template <bool STATS, bool SPILL, bool CULL>
 __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t tri_base4,
-                               const RaySetup& R, float range_max,
+                               const RaySetup& R, float range_max, float hit_pad,
                                uint32_t* lds_stack, int stack_lds, uint32_t* spill, int spill_stride, int gray,
                                unsigned& n_nodes, unsigned& n_tris, unsigned* wstat = nullptr)
 {
@@ -189,8 +189,25 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
             const V3 qvec = v_cross(tvec, e1);
             const float v = v_dot(d, qvec) * inv;
             const float tt = v_dot(e2, qvec) * inv;
-            const bool ok = ((uint32_t)q < cnt) && (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
-                            (tt > 0.0f && tt <= range_max);
+            bool ok = ((uint32_t)q < cnt) && (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
+                      (tt > 0.0f && tt <= range_max);
+            // Grazing guard (round 5): a ray within 0.3 degrees of the triangle's plane -- det^2 < 2.5e-5 |e1 x e2|^2, the
+            // threshold rides in the record's spare word (k_tri_graze) -- makes Moeller-Trumbore ill-conditioned: its
+            // barycentric test can accept a point centimetres outside the triangle, outside the padded box any hierarchy
+            // holds the triangle in (seed 307 of round 4's nearest-hit fuzz).  Such a hit counts only if its point lies in
+            // the triangle's box padded by hit_pad (= half the builders' padding), which makes the nearest hit a property
+            // of the mesh alone, not of the tree; the oracle applies the same rule with the same un-fused arithmetic.
+            // Wave-uniform branch, taken by ~1 leaf step in 50: 4 instructions on the path everybody runs
+            const bool graze = ok && (det * det < C.w);
+            if (__builtin_amdgcn_ballot_w64(graze) != 0ull) {
+                const V3 ph = v_add(o, v_scale(d, tt));
+                const V3 v1 = v_add(v0, e1), v2 = v_add(v0, e2);
+                const bool inside =
+                    ph.x >= fminf(v0.x, fminf(v1.x, v2.x)) - hit_pad && ph.x <= fmaxf(v0.x, fmaxf(v1.x, v2.x)) + hit_pad &&
+                    ph.y >= fminf(v0.y, fminf(v1.y, v2.y)) - hit_pad && ph.y <= fmaxf(v0.y, fmaxf(v1.y, v2.y)) + hit_pad &&
+                    ph.z >= fminf(v0.z, fminf(v1.z, v2.z)) - hit_pad && ph.z <= fmaxf(v0.z, fmaxf(v1.z, v2.z)) + hit_pad;
+                if (graze && !inside) ok = false;
+            }
             // quad-wide nearest (t, then lower face index) in two 32-bit rounds: t is positive or +inf, so its
             // order is the unsigned order of its bits -> minimum over the quad with two DPP mins; then, among
             // the lanes that hold that minimum, the lowest (face << 2 | lane): the low bits name the winning
@@ -294,7 +311,7 @@ __device__ __forceinline__ void trace_group(const Params& P, const int pass, con
     unsigned ws[4] = { 0, 0, 0, 0 };
     if (active) {
         const int gray = ((FIRST ? 0 : seg_y) * gdim_x + (int)gx) * kRaysPerBlock + r;   // spill column of this ray slot
-        const Hit h = traverse<STATS, SPILL, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
+        const Hit h = traverse<STATS, SPILL, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, P.hit_pad, lds_stack, P.stack_lds,
                                        P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
@@ -404,7 +421,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_debug_trace(const Params P, c
     const V3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
     unsigned nn = 0, nt = 0;
     const RaySetup R = ray_setup(o, d);
-    const Hit h = traverse<STATS, true, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, lds_stack, P.stack_lds,
+    const Hit h = traverse<STATS, true, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, P.hit_pad, lds_stack, P.stack_lds,
                                   P.spill, P.spill_stride, i, nn, nt);
     if ((threadIdx.x & 3) == 0) {
         if (out_t) out_t[i] = (h.tri != 0xFFFFFFFFu) ? h.t : -1.0f;
@@ -1353,11 +1370,22 @@ __global__ void k_encode_refs(Node4* nodes, size_t n_children, uint32_t tri_base
     if (r & kLeafFlag) ref = (r & 0xF0000000u) | (tri_base4 + 3u * (r & 0x0FFFFFFFu));
     else ref = r * 8u;
 }
-void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s)
+// ... and the grazing threshold of every triangle record into its spare word: 2.5e-5 |e1 x e2|^2 (see traverse)
+__global__ void k_tri_graze(TriRec* tris, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 e1 = { tris[i].e1[0], tris[i].e1[1], tris[i].e1[2] }, e2 = { tris[i].e2[0], tris[i].e2[1], tris[i].e2[2] };
+    const V3 c = v_cross(e1, e2);
+    tris[i].pad = __float_as_uint(2.5e-5f * v_dot(c, c));
+}
+void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s, size_t n_tris)
 {
     const size_t n = n_nodes * 4;
     if (n == 0) return;
     hipLaunchKernelGGL(k_encode_refs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nodes, n, tri_base4);
+    if (n_tris) hipLaunchKernelGGL(k_tri_graze, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, s,
+                                   reinterpret_cast<TriRec*>(reinterpret_cast<float4*>(nodes) + tri_base4), n_tris);
 }
 
 void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)

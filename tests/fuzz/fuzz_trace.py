@@ -82,29 +82,13 @@ def run(n_seeds=20, first=0, verbose=True):
             hit = want_t >= 0
             ok = np.array_equal(t[hit], want_t[hit]) and np.array_equal(face[hit], want_f[hit]) and (t[~hit] < 0).all()
             if not ok:
-                # One class of difference is inherent to ANY hierarchy against a test-everything loop: a ray that GRAZES a
-                # triangle's plane (|d . n| < 2e-4) makes Moeller-Trumbore ill-conditioned -- its barycentric test can accept
-                # a "hit" whose point o + t d lies centimetres outside the triangle (and outside its padded box, which the
-                # hierarchy rightly skips).  Such rays are reported apart (seed 307 of round 4: 1 ray in 6M; both builders,
-                # round 3's library as well); anything else is a mismatch.
+                # (Until round 4 one class of difference was reported apart: a ray that grazes a triangle's plane makes
+                # Moeller-Trumbore accept a point outside the triangle's padded box, which a hierarchy skips -- seed 307.  The
+                # grazing guard of round 5 made the hit definition independent of the structure: every difference is a mismatch.)
                 idx = np.nonzero((t != want_t) | ((face != want_f) & hit))[0]
-                real = []
-                for i in idx:
-                    fo = int(want_f[i])
-                    if fo < len(f):
-                        tri = v[f[fo]].astype(np.float64)
-                        nrm = np.cross(tri[1] - tri[0], tri[2] - tri[0]); nrm /= max(np.linalg.norm(nrm), 1e-300)
-                        pt = o[i].astype(np.float64) + float(want_t[i]) * d[i].astype(np.float64)
-                        outside = np.maximum(np.maximum(tri.min(0) - pt, pt - tri.max(0)), 0.0).max()
-                        if abs(float(np.dot(nrm, d[i].astype(np.float64)))) < 2e-4 and outside > 1e-3:
-                            print("grazing ray (not counted): seed", seed, builder, "ray", int(i), "gpu", t[i], face[i], "oracle", want_t[i], want_f[i],
-                                  "|d.n| %.2e, oracle's point %.2e outside its triangle's box" % (abs(float(np.dot(nrm, d[i]))), outside))
-                            continue
-                    real.append(int(i))
-                if real:
-                    bad += 1
-                    i = real[0]
-                    print("MISMATCH seed", seed, builder, "ray", i, "gpu", t[i], face[i], "oracle", want_t[i], want_f[i], "o", o[i], "d", d[i])
+                bad += 1
+                i = int(idx[0])
+                print("MISMATCH seed", seed, builder, "ray", i, "gpu", t[i], face[i], "oracle", want_t[i], want_f[i], "o", o[i], "d", d[i])
     if verbose:
         print("trace fuzz: %d scenes x 2 builders, %d mismatching" % (n_seeds, bad))
     return bad
