@@ -15,10 +15,12 @@ batches in flight on 4 streams.  Mesh, BVH, parameters and beam samples are resi
 region; poses are 7 floats passed as kernel arguments.  Timing bracket = the reference's stopwatch
 (RadarCPU.cpp:147-148 -> :550).
 
-`value`: images left in HBM ("inputs resident, output resident": the bench contract).  Because the reference's
-simulate() ends with the image in HOST memory (m_polar_image, RadarCPU.cpp:542,555-561), the same line carries
-`host_resident`: the same K steps timed THROUGH the last D2H copy of every image into page-locked host memory
-(rr_simulate_batch_host_async: the images ride out on the trace launches of the lane's next batch, a few waves with one store in flight each), and `single_pose`: one pose per
+`value` (round 5): the bracket of SURVEY §8(d) = the reference's stopwatch -- the reference's simulate() ends with the image in
+HOST memory (m_polar_image, RadarCPU.cpp:542,555-561), so the K steps are timed THROUGH the last D2H copy of every image into
+page-locked host memory (N = 1: rr_simulate_batch_host_async; N > 1: every rank delivers the frames it assembled,
+AzimuthShard(host_out=True); either way the images ride out on the trace launches of the next batch on the same stream, a few
+waves with one store in flight each).  Inputs (mesh, tree, parameters, beam) are resident in HBM before the timed region.
+The same line carries `hbm_resident` (the same steps with the images left in HBM: `value` of rounds 1-4) and `single_pose`: one pose per
 launch set (the latency-oriented shape a live ROS node would use).  Before every timed region the GPU is
 pre-warmed by wall time (>= 0.3 s of steps, untimed) so that `--steps 20` reads sustained clocks.
 
@@ -31,6 +33,10 @@ per-frame gathers fused) hands frames d*F.. to rank d -- per-GPU work per step i
 `python bench.py --gpus N` with no launcher around it starts its own N ranks (a `torch.distributed.run` child, before this
 process touches the GPU) and exits 3 with one line when the box has fewer than N GPUs.  stdout carries the JSON line and
 nothing else (RCCL's version banner is sent to stderr).
+
+N > 1 also carries `rccl` -- what a reader needs to believe RCCL saw N ranks: world size and backend as torch.distributed
+reports them, every rank's device (index, name, PCI bus id), the collective and its bytes, every rank's own images/s and the
+slowest rank -- and `n1_reference`, the N = 1 figure of the same workload from profiles/.
 
 Also on the line: `single_frame_sync` (ONE synchronous rr_simulate per frame: the reference's own call shape,
 radar_simulator.cpp:197-212) and `strong_scaling_proxy` (a block of 400/N azimuth columns alone on the GPU against the
@@ -152,6 +158,42 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_block(rank, world, device_desc, collective, bytes_per_collective, own_images_per_s, group=None):
+    """The `rccl` object of the N > 1 line (every rank calls it; rank 0 gets the dict, the others None).  Uses only
+    torch.distributed object collectives, so the world-2 gloo test on the CPU runs this very function."""
+    import torch.distributed as dist
+    mine = dict(device_desc)
+    mine["rank"] = int(rank)
+    mine["images_per_s"] = round(float(own_images_per_s), 2)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    if rank != 0:
+        return None
+    everyone = sorted(everyone, key=lambda d: d["rank"])
+    rates = [d.pop("images_per_s") for d in everyone]
+    return {"world_size": int(dist.get_world_size(group)), "backend": str(dist.get_backend(group)),
+            "ranks": everyone, "distinct_devices": len({(d.get("pci_bus_id"), d.get("device_index")) for d in everyone}),
+            "collective": collective, "bytes_per_collective": int(bytes_per_collective),
+            "per_rank_images_per_s": rates, "slowest_rank": int(min(range(world), key=lambda r: rates[r])),
+            "what": "world size and backend as torch.distributed reports them; one entry per rank with the device it ran on; "
+                    "per_rank_images_per_s = the frames a rank assembled and delivered / its OWN wall time for the timed steps "
+                    "(value uses the slowest rank's time)"}
+
+
+def n1_reference(workload):
+    """The N = 1 figure of the same workload recorded under profiles/ (newest round first), for the N > 1 line."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_%s.json" % workload)), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("n_gpus") == 1:
+                return {"value": d["value"], "unit": d.get("unit"), "images": d.get("config", {}).get("images"),
+                        "source": os.path.relpath(f, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="target_10M_400x200_4pass", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the host_resident / single_pose regions")
+    ap.add_argument("--no-extras", action="store_true", help="skip the hbm_resident / single_pose regions")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--ambient-noise", type=int, default=2)
     ap.add_argument("--strong", action="store_true", help="N>1: one frame per batch + all-gather")
@@ -221,9 +263,12 @@ def main():
     n_tris = len(scene["faces"])
 
     dev = torch.device("cuda", local_rank)
+    # the timed steps end with every image in HOST memory (the reference's stopwatch bracket).  N = 1: the
+    # library's own host delivery (rr_simulate_batch_host_async); N > 1: every rank delivers the frames it assembled
+    host_mode = world == 1 and not args.force_slots
     shard = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, rank, world, dev,
                          force_collective=args.force_slots, strong=args.strong,
-                         frames_per_rank=args.frames_per_rank, n_slots=args.slots)
+                         frames_per_rank=args.frames_per_rank, n_slots=args.slots, host_out=not host_mode)
     fpb = shard.frames_per_step                 # frames of one batch (all ranks)
     bps = max(1, args.batches_per_step)
     fps = fpb * bps                             # frames per step (all ranks)
@@ -232,6 +277,33 @@ def main():
         for b in range(bps):
             shard.step([poses[((k * bps + b) * fpb + f) % len(poses)] for f in range(fpb)], None,
                        done_event=done if b == bps - 1 else None)
+
+    if host_mode:
+        F = args.frames_per_rank
+        h_streams = [torch.cuda.Stream(device=dev) for _ in range(args.slots)]
+        # a ring of host buffers twice as deep as the batches in flight: the consumer side (rr_wait_host before a
+        # buffer is handed out again) then never stalls the producer
+        hosts = [native.HostImages((F, cfg.n_cells, params.N_ANGLES)) for _ in range(2 * args.slots)]
+        h_state = {"n": 0}
+
+        def step_main(k, done=None):
+            for b in range(bps):
+                n = h_state["n"]
+                h_state["n"] += 1
+                h = hosts[n % len(hosts)]
+                ctx.wait_host(h.ptr)                  # the images this buffer received 2 x slots batches ago are complete
+                st_ = h_streams[n % args.slots]
+                ctx.simulate_batch_host_async([poses[((k * bps + b) * F + f) % len(poses)] for f in range(F)], h.ptr, st_.cuda_stream)
+                if done is not None and b == bps - 1:
+                    done.record(st_)
+
+        def finish_main():
+            ctx.wait_host(None)                       # through the last D2H copy
+    else:
+        step_main = step
+
+        def finish_main():
+            shard.flush_host()
 
     def prewarm(fn, seconds=PREWARM_S, collective=False):
         """untimed: at least `seconds` of steps so the timed region starts at sustained clocks.  With a collective
@@ -290,7 +362,8 @@ def main():
     # (timing mode 2: pooled hipExtLaunchKernel events around the k_trace launches only, on the launch stream)
     done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     ctx.reserve_timing_events(2 * n_pass * bps * args.steps + 64)
-    prewarm(step, collective=True)
+    prewarm(step_main, collective=True)
+    finish_main(); torch.cuda.synchronize()
     ctx.set_timing_mode(2)
     ctx.kernel_time("trace", reset=True); ctx.kernel_time("trace0", reset=True)
     if world > 1:
@@ -299,8 +372,10 @@ def main():
     done[0].record(torch.cuda.current_stream())
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k, done[k + 1])
+        step_main(k, done[k + 1])
+    finish_main()                                     # ... through the last D2H copy of the last image
     torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0                  # this rank's own time (the line's `value` uses the slowest rank's)
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
@@ -325,39 +400,23 @@ def main():
         wave_passes_batch = wave_passes_batch_rank
 
     # ---- N = 1 extras: the image delivered to host memory; one pose per launch set ---------------------------
-    host_res = single = sync1 = proxy = None
+    hbm_res = single = sync1 = proxy = None
     if world == 1 and not args.no_extras and not args.force_slots:
         npx = cfg.n_cells * params.N_ANGLES
-        F = args.frames_per_rank
-        streams = [torch.cuda.Stream(device=dev) for _ in range(args.slots)]
-        # a ring of host buffers twice as deep as the batches in flight: the consumer side (rr_wait_host before a
-        # buffer is handed out again) then never stalls the producer
-        hosts = [native.HostImages((F, cfg.n_cells, params.N_ANGLES)) for _ in range(2 * args.slots)]
-        state = {"n": 0}
-
-        def step_host(k):
-            for b in range(bps):
-                n = state["n"]
-                state["n"] += 1
-                h = hosts[n % len(hosts)]
-                ctx.wait_host(h.ptr)                  # the images this buffer received 2 x slots batches ago are complete
-                ctx.simulate_batch_host_async([poses[((k * bps + b) * F + f) % len(poses)] for f in range(F)],
-                                              h.ptr, streams[n % args.slots].cuda_stream)
-        prewarm(step_host)
-        ctx.wait_host(None); torch.cuda.synchronize()
-        th0 = time.perf_counter()
-        for k in range(args.steps):
-            step_host(k)
-        ctx.wait_host(None)                           # through the last D2H copy
-        torch.cuda.synchronize()
-        th1 = time.perf_counter()
-        host_res = {"value": round(args.steps * bps * F / (th1 - th0), 2), "unit": "images/s",
-                    "ms_per_step": round(1e3 * (th1 - th0) / args.steps, 4),
-                    "what": "same steps, every mono8 image delivered to page-locked host memory (rr_simulate_batch_host_async: "
-                            "trickled out by a few waves of the next batch's trace launches), timed through the last copy",
-                    "d2h_GBps": round(args.steps * bps * F * npx / (th1 - th0) / 1e9, 3)}
         for h in hosts:
             h.close()
+        # the same steps with the images left in HBM (`value` of rounds 1-4)
+        prewarm(step)
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        torch.cuda.synchronize()
+        th1 = time.perf_counter()
+        hbm_res = {"value": round(args.steps * fps / (th1 - th0), 2), "unit": "images/s",
+                   "ms_per_step": round(1e3 * (th1 - th0) / args.steps, 4),
+                   "what": "same steps, every mono8 image assembled and LEFT IN HBM (no D2H copy in the timed region): the "
+                           "`value` of rounds 1-4"}
         one = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, 0, 1, dev, frames_per_rank=1, n_slots=args.slots)
         n1 = max(args.steps, 16)
         prewarm(lambda k: one.step([poses[k % len(poses)]], None))
@@ -408,6 +467,23 @@ def main():
         proxy["what"] = ("one frame's kernel chain for a block of 400/N columns alone on the GPU vs all 400: an upper bound of the "
                          "strong-scaling speed-up of ONE frame on N GPUs (efficiency = strong_ceiling_N); the default N > 1 mode of "
                          "this bench is WEAK scaling (N x frames per batch), which keeps every GPU's launches as large as at N = 1")
+
+    # ---- N > 1: what a reader needs to believe RCCL saw N ranks ------------------------------------------------
+    rccl = None
+    if world > 1 or args.force_slots:
+        props = torch.cuda.get_device_properties(local_rank)
+        bus = None
+        if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            bus = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        desc = {"device_index": int(local_rank), "name": props.name, "pci_bus_id": bus,
+                "uuid": str(getattr(props, "uuid", "")) or None, "pid": os.getpid()}
+        n_loc = shard.n_loc
+        if shard.strong:
+            coll, nbytes = "all_gather_into_tensor (one per frame)", n_loc * cfg.n_cells
+        else:
+            coll, nbytes = "all_to_all_single (one per batch: frames d*F.. -> rank d)", fpb * n_loc * cfg.n_cells
+        own = args.steps * bps * shard.fpr / t_own        # frames THIS rank assembled and delivered per second of its own time
+        rccl = rccl_block(rank, world, desc, coll, nbytes, own)
 
     out = None
     if rank == 0:
@@ -519,7 +595,8 @@ def main():
                        "range_bins": int(cfg.n_cells), "rays_per_beam": n_rays, "passes": n_pass,
                        "ambient_noise": int(cfg.ambient_noise),
                        "frames_per_step": fps, "frames_per_batch": fpb, "batches_per_step": bps,
-                       "images": "resident in HBM",
+                       "images": "delivered to page-locked host memory; timed through the last D2H copy (SURVEY §8d bracket = the reference's stopwatch, RadarCPU.cpp:147-550)",
+                       "d2h_GBps": round(img_per_s * cfg.n_cells * params.N_ANGLES / 1e9, 3),
                        "sharding": ("single GPU" if world == 1 else
                                     "azimuth columns x%d, 1 frame/batch + 1 all-gather" % world if args.strong else
                                     "azimuth columns x%d, %d frames/batch, 1 all_to_all/batch (frame f -> rank f)" % (world, fpb))},
@@ -530,7 +607,9 @@ def main():
                                       "p90": round(fps / (1e-3 * pct(periods_ms, 0.1)), 2) if periods_ms else None,
                                       "basis": "cadence of step completions (hip events), differenced over windows of %d completions" % win},
             "prewarm_s": PREWARM_S,
-            "host_resident": host_res,
+            "rccl": rccl,
+            "n1_reference": n1_reference(args.workload) if world > 1 else None,
+            "hbm_resident": hbm_res,
             "single_pose": single,
             "single_frame_sync": sync1,
             "strong_scaling_proxy": proxy,

@@ -182,6 +182,18 @@ int rr_simulate_columns_device(rr_ctx* ctx, const float pose_qxyzw_t[7], int az_
 int rr_simulate_batch_columns_device(rr_ctx* ctx, const float* poses, int n_frames, int az_begin, int az_end,
                                      uint8_t* d_cols_u8, void* stream);
 
+/* The same, carrying a device -> host copy of the CALLER's: carry_bytes from d_carry_src (device memory written by earlier
+ * work on `stream`, e.g. the images this rank assembled from its previous batch on this stream) to h_carry_dst (page-locked:
+ * rr_host_alloc) travel on this batch's later-pass trace launches -- a few waves with one 1-KB store in flight each, the
+ * route rr_simulate_batch_host_async uses, which keeps the stores of the running kernels from queueing behind a bulk
+ * copy.  The bytes are complete once `stream` has passed this call's launches.  With a single ray-cast pass, a pageable
+ * destination or sizes that are not multiples of 16 the copy is a plain hipMemcpyAsync ahead of the batch.  This is how
+ * the sharded step loop (one process per GPU, radarays_ros_amd/dist.py) leaves every frame in HOST memory like the
+ * reference's simulate() does (RadarCPU.cpp:542,555-561) without paying a copy per batch. */
+int rr_simulate_batch_columns_carry_device(rr_ctx* ctx, const float* poses, int n_frames, int az_begin, int az_end,
+                                           uint8_t* d_cols_u8, void* stream,
+                                           const void* d_carry_src, void* h_carry_dst, size_t carry_bytes);
+
 /* Whole frames of n_frames (1..RR_MAX_BATCH) poses in one set of launches, everything on `stream` (no internal
  * streams: callers that want several batches in flight issue them on several streams, 4 is the measured
  * optimum): d_imgs_u8 = [n_frames][n_cells][n_angles].  The throughput entry point for offline generation

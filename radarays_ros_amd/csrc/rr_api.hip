@@ -1116,6 +1116,41 @@ int rr_simulate_batch_columns_device(rr_ctx* c, const float* poses, int n_frames
     return 0;
 }
 
+int rr_simulate_batch_columns_carry_device(rr_ctx* c, const float* poses, int n_frames, int az_begin, int az_end,
+                                           uint8_t* d_cols_u8, void* stream, const void* d_carry_src, void* h_carry_dst, size_t carry_bytes)
+{
+    int rc = check_ready(c); if (rc) return rc;
+    if (!poses || !d_cols_u8) return fail(c, -3, "rr_simulate_batch_columns_carry_device: null poses/output");
+    if (carry_bytes && (!d_carry_src || !h_carry_dst)) return fail(c, -3, "rr_simulate_batch_columns_carry_device: null carry pointer");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = upload_tables(c); if (rc) return rc;
+    const size_t li = c->next_lane++ % c->lanes.size();
+    Lane& L = c->lanes[li];
+    { int rcf = flush_deferred(c, L); if (rcf) return rcf; }
+    c->last_lane = li;
+    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
+    // the carried copy rides on the later-pass trace launches (a few waves, one 1-KB store per wave in flight: Params::copy_src)
+    // when there are such launches and the destination is page-locked; else it is a plain copy ahead of the batch
+    bool fold = carry_bytes > 0 && c->copy_blocks > 0 && eff_config(c).n_reflections >= 2 && carry_bytes % 16 == 0 && !c->stats_mode &&
+                ((uintptr_t)d_carry_src | (uintptr_t)h_carry_dst) % 16 == 0;
+    if (fold) {
+        hipPointerAttribute_t at;
+        fold = hipPointerGetAttributes(&at, h_carry_dst) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+    }
+    if (carry_bytes && !fold) RR_HIP(c, hipMemcpyAsync(h_carry_dst, d_carry_src, carry_bytes, hipMemcpyDeviceToHost, s));
+    rc = run_frame(c, L, poses, az_begin, az_end, d_cols_u8, nullptr, s, n_frames, nullptr, 0, false,
+                   fold ? (const uint8_t*)d_carry_src : nullptr, fold ? (uint8_t*)h_carry_dst : nullptr, fold ? carry_bytes : 0);
+    if (rc) {
+        if (fold) RR_HIP(c, hipMemcpyAsync(h_carry_dst, d_carry_src, carry_bytes, hipMemcpyDeviceToHost, s));    // refused before any launch: the copy still happens
+        return rc;
+    }
+    RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+    L.pending_consume = true;
+    return 0;
+}
+
 int rr_simulate_batch_device(rr_ctx* c, const float* poses, int n_frames, uint8_t* d_imgs_u8, void* stream)
 {
     int rc = check_ready(c); if (rc) return rc;

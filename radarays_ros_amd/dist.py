@@ -18,6 +18,13 @@ One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm).  torch 
 plumbing here: device buffers, streams, the collective.  Steps are pipelined over a
 few slots (own HIP stream + buffers) so the collective of step k overlaps the
 kernels of step k+1.
+
+`host_out=True`: the reference's simulate() ends with the image in HOST memory
+(m_polar_image, RadarCPU.cpp:542,555-561), so every rank also delivers the frames it
+assembled to page-locked host memory.  A copy behind each step costs ~7 % of the frame
+rate, so the images a slot assembled ride out on the later-pass trace
+launches of the slot's NEXT step (rr_simulate_batch_columns_carry_device, same stream:
+ordered behind the assemble that wrote them); `flush_host()` sends what is still waiting.
 """
 import contextlib
 
@@ -60,6 +67,11 @@ class _Slot:
         self.recv = torch.zeros((max(n_frames * n_local, n_angles), n_cells), dtype=torch.uint8, device=device)
         self.images = torch.zeros((n_images, n_cells, n_angles), dtype=torch.uint8, device=device)
         self.done = torch.cuda.Event() if device.type == "cuda" else None
+        # host_out: where this slot's images end up, whether a set is still waiting in `images`, and the step it belongs to
+        self.host = None
+        self.host_pending = False
+        self.step_no = -1
+        self.host_step_no = -1
 
 
 class AzimuthShard:
@@ -76,7 +88,7 @@ class AzimuthShard:
                 (every rank ends up with it)."""
 
     def __init__(self, ctx, n_cells, n_angles, rank, world, device, n_slots=4, strong=False,
-                 frames_per_rank=1, force_collective=False):
+                 frames_per_rank=1, force_collective=False, host_out=False):
         self.ctx, self.n_cells, self.n_angles = ctx, n_cells, n_angles
         self.rank, self.world, self.device = rank, world, device
         self.begin, self.end = partition(n_angles, world, rank)
@@ -91,6 +103,10 @@ class AzimuthShard:
         self.slots = [_Slot(self.frames_per_step, self.fpr, self.n_loc, n_cells, n_angles, device)
                       for _ in range(n_slots)]
         self.last = None
+        self.host_out = bool(host_out)
+        if self.host_out:
+            for s in self.slots:
+                s.host = torch.zeros((self.fpr, n_cells, n_angles), dtype=torch.uint8, pin_memory=(device.type == "cuda"))
 
     def frame(self, pose, stream=None):
         """Single-frame step (frames_per_step == 1)."""
@@ -111,7 +127,14 @@ class AzimuthShard:
                 cols = gather_columns(s.block[0], self.n_angles, self.world, out=s.recv[:self.n_angles])
                 self.ctx.assemble_image_device(cols.data_ptr(), s.images[0].data_ptr(), sp)
             else:
-                self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
+                if self.host_out and s.host_pending:
+                    # the images this slot assembled n_slots steps ago leave on this step's trace launches
+                    self.ctx.simulate_batch_columns_carry_device(poses, self.begin, self.end, s.block.data_ptr(), sp,
+                                                                 s.images.data_ptr(), s.host.data_ptr(), s.images.numel())
+                    s.host_pending = False
+                    s.host_step_no = s.step_no
+                else:
+                    self.ctx.simulate_batch_columns_device(poses, self.begin, self.end, s.block.data_ptr(), sp)
                 if self.collective:
                     # frames d*fpr .. d*fpr+fpr-1 go to rank d; I receive [source rank][fpr][n_loc][C],
                     # source-rank order == azimuth order
@@ -122,12 +145,43 @@ class AzimuthShard:
                 # all fpr frames of this rank in one launch
                 self.ctx.assemble_frames_device(src.data_ptr(), nl, self.fpr * nl * C, self.fpr, nl * C,
                                                 s.images.data_ptr(), sp)
+            s.step_no = self.k - 1
+            if self.host_out:
+                if self.strong:          # latency mode: one frame, delivered at once
+                    s.host.copy_(s.images, non_blocking=True)
+                    s.host_step_no = s.step_no
+                else:
+                    s.host_pending = True
             if s.done is not None:
                 s.done.record(s.stream)
             if done_event is not None and s.stream is not None:
                 done_event.record(s.stream)
         self.last = s
         return s.images
+
+    def flush_host(self):
+        """host_out: deliver the images that are still waiting on their slots (plain copies on the slots' streams) and wait
+        for every delivery.  Afterwards slot.host holds the images of step slot.host_step_no for every slot."""
+        if not self.host_out:
+            return
+        for s in self.slots:
+            if s.host_pending:
+                with (torch.cuda.stream(s.stream) if s.stream is not None else contextlib.nullcontext()):
+                    s.host.copy_(s.images, non_blocking=True)
+                s.host_pending = False
+                s.host_step_no = s.step_no
+        for s in self.slots:
+            if s.stream is not None:
+                s.stream.synchronize()
+
+    def host_images(self, step_no):
+        """The host tensor [fpr][n_cells][n_angles] holding this rank's images of step `step_no`, or None when that step has
+        not been delivered (yet) or its slot has been handed to a later step.  Valid after flush_host(), or once the step
+        n_slots later on the same slot has completed."""
+        for s in self.slots:
+            if s.host is not None and s.host_step_no == step_no:
+                return s.host
+        return None
 
     def wait(self, stream=None):
         """Make `stream` wait for the most recently enqueued step."""

@@ -17,6 +17,7 @@ SYMBOLS = [
     "rr_abi_version", "rr_default_config", "rr_create", "rr_destroy", "rr_last_error",
     "rr_set_mesh", "rr_set_mesh_gpu", "rr_copy_mesh", "rr_set_materials", "rr_set_config", "rr_set_beam_samples",
     "rr_set_noise_offsets", "rr_set_motion_poses", "rr_simulate", "rr_simulate_columns_device", "rr_simulate_batch_columns_device",
+    "rr_simulate_batch_columns_carry_device",
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_get_trace_grid", "rr_set_timing_mode",
@@ -120,6 +121,7 @@ def lib():
     L.rr_simulate.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(RRStats)]
     L.rr_simulate_columns_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.rr_simulate_batch_columns_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.rr_simulate_batch_columns_carry_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_size_t]
     L.rr_assemble_image_device.argtypes = [vp, vp, vp, vp]
     L.rr_assemble_blocks_device.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, vp]
     L.rr_assemble_frames_device.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_size_t, vp, vp]
@@ -336,6 +338,12 @@ class Context:
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
         self._ck(self._L.rr_simulate_batch_columns_device(self._h, p.ctypes.data, len(p), az_begin, az_end,
                                                           d_cols_u8_ptr, stream))
+
+    def simulate_batch_columns_carry_device(self, poses, az_begin, az_end, d_cols_u8_ptr, stream, d_carry_src, h_carry_dst, carry_bytes):
+        """rr_simulate_batch_columns_carry_device: the batch's later-pass trace launches carry a device -> host copy"""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        self._ck(self._L.rr_simulate_batch_columns_carry_device(self._h, p.ctypes.data, len(p), az_begin, az_end, d_cols_u8_ptr, stream,
+                                                                d_carry_src, h_carry_dst, int(carry_bytes)))
 
     def assemble_image_device(self, d_cols_u8_ptr, d_img_ptr, stream=None):
         self._ck(self._L.rr_assemble_image_device(self._h, d_cols_u8_ptr, d_img_ptr, stream))

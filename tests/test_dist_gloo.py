@@ -146,6 +146,11 @@ class _MockCtx:
         for f, p in enumerate(poses):
             v[f * n:(f + 1) * n] = self._cols(p, b, e).ravel()
 
+    def simulate_batch_columns_carry_device(self, poses, b, e, ptr, sp, src, dst, nbytes):
+        self._view(dst, nbytes)[:] = self._view(src, nbytes)       # (the real call trickles it out on its trace launches)
+        self.carried = getattr(self, "carried", 0) + 1
+        self.simulate_batch_columns_device(poses, b, e, ptr, sp)
+
     def assemble_blocks_device(self, ptr, n_loc, stride, img_ptr, sp):
         img = self._view(img_ptr, self.C * self.A).reshape(self.C, self.A)
         for a in range(self.A):
@@ -190,6 +195,22 @@ def _worker_shard(rank, world, port, out_dir):
         imgs = weak.step(step_poses)
         for j in range(2):                               # I own frames rank*2 + j of the step
             ok &= int(np.array_equal(imgs[j].numpy(), full(step_poses[rank * 2 + j])))
+    # host_out: every frame also reaches host memory -- the images of step k ride out with step k + n_slots on the same slot,
+    # flush_host() sends the rest
+    hosty = AzimuthShard(ctx, cfg.n_cells, A, rank, world, dev, n_slots=2, frames_per_rank=2, host_out=True)
+    kept = {}
+    for k in range(5):
+        step_poses = [poses[(k * 4 + f) % 8] for f in range(4)]
+        kept[k] = [full(step_poses[rank * 2 + j]) for j in range(2)]
+        hosty.step(step_poses)
+        if k >= 2:                                       # step k - 2 has been carried out by this call
+            h = hosty.host_images(k - 2)
+            ok &= int(h is not None and all(np.array_equal(h[j].numpy(), kept[k - 2][j]) for j in range(2)))
+    ok &= int(ctx.carried == 3 and hosty.host_images(4) is None)
+    hosty.flush_host()
+    for k in (3, 4):
+        h = hosty.host_images(k)
+        ok &= int(h is not None and all(np.array_equal(h[j].numpy(), kept[k][j]) for j in range(2)))
     strong = AzimuthShard(ctx, cfg.n_cells, A, rank, world, dev, n_slots=2, strong=True)
     assert strong.frames_per_step == 1
     for k in range(2):
@@ -211,3 +232,47 @@ def test_two_rank_azimuth_shard_step_loop(tmp_path, oracle):
     mp.spawn(_worker_shard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert np.load(os.path.join(str(tmp_path), "shard%d.npy" % r))[0] == 1
+
+
+def _worker_rccl_block(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    desc = {"device_index": rank, "name": "AMD Instinct MI355X", "pci_bus_id": "0000:%02x:00" % (5 + 8 * rank), "uuid": None, "pid": os.getpid()}
+    blk = bench.rccl_block(rank, world, desc, "all_to_all_single (one per batch: frames d*F.. -> rank d)", 16 * 200 * 3424,
+                           4000.0 + 100.0 * (1 - rank))
+    if rank == 0:
+        import json
+        with open(os.path.join(out_dir, "rccl.json"), "w") as f:
+            json.dump(blk, f)
+    else:
+        assert blk is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_rccl_block_schema_on_two_ranks(tmp_path):
+    """The `rccl` object of the N > 1 bench line, built by bench.rccl_block on a world-2 gloo group:
+    world size and backend come from torch.distributed, one entry per rank with its device, per-rank rates, slowest rank."""
+    import json
+    port = _free_port()
+    mp.spawn(_worker_rccl_block, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    b = json.load(open(os.path.join(str(tmp_path), "rccl.json")))
+    assert set(b) == {"world_size", "backend", "ranks", "distinct_devices", "collective", "bytes_per_collective",
+                      "per_rank_images_per_s", "slowest_rank", "what"}
+    assert b["world_size"] == 2 and b["backend"] == "gloo" and b["distinct_devices"] == 2
+    assert [r["rank"] for r in b["ranks"]] == [0, 1] and [r["device_index"] for r in b["ranks"]] == [0, 1]
+    assert all(set(r) == {"rank", "device_index", "name", "pci_bus_id", "uuid", "pid"} for r in b["ranks"])
+    assert b["ranks"][0]["pid"] != b["ranks"][1]["pid"]                  # one process per GPU
+    assert b["per_rank_images_per_s"] == [4100.0, 4000.0] and b["slowest_rank"] == 1
+    assert b["bytes_per_collective"] == 16 * 200 * 3424 and b["collective"].startswith("all_to_all_single")
+
+
+def test_bench_n1_reference_reads_profiles():
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    r = bench.n1_reference("target_10M_400x200_4pass")
+    assert r is not None and r["value"] > 1000 and r["source"].startswith("profiles/")
+    assert bench.n1_reference("no_such_workload") is None

@@ -233,15 +233,25 @@ def _shard_worker(rank, world, port, strong, out_dir):
     c = native.Context(rank)
     _setup(c, s, cfg, materials_for(s), golden_beams(60), noise)
     fpr = 1 if strong else 2
-    sh = AzimuthShard(c, cfg.n_cells, 400, rank, world, dev, n_slots=3, strong=strong, frames_per_rank=fpr)
+    sh = AzimuthShard(c, cfg.n_cells, 400, rank, world, dev, n_slots=3, strong=strong, frames_per_rank=fpr, host_out=True)
     fps = sh.frames_per_step
     steps = [[poses[(k * fps + f) % len(poses)] for f in range(fps)] for k in range(5)]
-    outs = []
-    for st in steps:
+    outs, host_ok = [], True
+    for k, st in enumerate(steps):
         imgs = sh.step(st, None)
         sh.wait()
         torch.cuda.current_stream().synchronize()
         outs.append(imgs.cpu().numpy().copy())
+        # host delivery (bench.py's bracket): strong = at once; weak = carried out by the step n_slots later on the same slot
+        back = k if strong else k - 3
+        if back >= 0:
+            sh.slots[k % 3].stream.synchronize()
+            h = sh.host_images(back)
+            host_ok = host_ok and h is not None and np.array_equal(h.numpy(), outs[back])
+    sh.flush_host()
+    for k in range(len(steps) - 3, len(steps)):
+        h = sh.host_images(k)
+        host_ok = host_ok and h is not None and np.array_equal(h.numpy(), outs[k])
     sh.close()
     # reference: the same frames through the single-GPU synchronous path of THIS rank's context
     ok = True
@@ -251,7 +261,7 @@ def _shard_worker(rank, world, port, strong, out_dir):
             c.set_noise_offsets(noise[f % 4] if not strong else noise[0])
             ref, _, _ = c.simulate(st[f])
             ok = ok and np.array_equal(outs[k][j], ref)
-    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([int(ok)]))
+    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([int(ok and host_ok)]))
     c.close()
     dist.barrier()
     dist.destroy_process_group()

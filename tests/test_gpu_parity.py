@@ -440,6 +440,21 @@ def test_sharded_slot_path_on_one_rank(native_lib):
         imgs = sh3.step(poses[4:6]); sh3.wait(); torch.cuda.synchronize()
         for f in range(2):
             assert np.array_equal(imgs[f].cpu().numpy(), want[4 + f])
+        # host_out (round 5): every frame also lands in page-locked host memory -- step k's images ride out on the trace
+        # launches of step k + n_slots (rr_simulate_batch_columns_carry_device), flush_host() sends the rest
+        sh4 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, n_slots=2, force_collective=True, frames_per_rank=2, host_out=True)
+        order = [(0, 1), (2, 3), (4, 5), (6, 0), (1, 3)]
+        for k, pr in enumerate(order):
+            sh4.step([poses[pr[0]], poses[pr[1]]])
+            if k >= 2:
+                sh4.slots[k % 2].stream.synchronize()
+                h = sh4.host_images(k - 2)
+                assert h is not None and all(np.array_equal(h[f].numpy(), want[order[k - 2][f]]) for f in range(2)), k
+        assert sh4.host_images(4) is None
+        sh4.flush_host()
+        for k in (3, 4):
+            h = sh4.host_images(k)
+            assert h is not None and all(np.array_equal(h[f].numpy(), want[order[k][f]]) for f in range(2)), k
         # strong mode (all-gather) on one rank
         sh2 = AzimuthShard(c, cfg.n_cells, 400, 0, 1, dev, force_collective=True, strong=True)
         img = sh2.frame(poses[2]); sh2.wait(); torch.cuda.synchronize()

@@ -13,7 +13,7 @@ for label, w in W:
     if not os.path.exists(f):
         continue
     d = json.load(open(f)); r = d["roofline"]; cb = d.get("cpu_baseline") or {}
-    hr, sp, sf, px = d.get("host_resident") or {}, d.get("single_pose") or {}, d.get("single_frame_sync") or {}, d.get("strong_scaling_proxy") or {}
+    hr, sp, sf, px = (d.get("hbm_resident") or d.get("host_resident") or {}), d.get("single_pose") or {}, d.get("single_frame_sync") or {}, d.get("strong_scaling_proxy") or {}
     fr = lambda x: "-" if x is None else "%.2f" % x
     u = (r.get("useful_issue_frac") or {}).get("value")
     print("| %s | %s (%s of %s) | **%s** | %s | %s | %s | %.2f G | `%s` %s / %s / %s | %.0f / %.0f us | %s |" % (
