@@ -259,7 +259,11 @@ int rr_simulate_material_sets(rr_ctx* ctx, const float pose[7], const rr_materia
  *   n_reflections  0..16 passes for this set, negative: the config's.  A set with fewer passes than the others simply
  *                  stops early (no live waves in the later launches); wave queues are sized for the largest
  * Image k is bit-identical to rr_set_materials / rr_set_beam_samples / rr_set_config(n_reflections) of set k followed
- * by rr_simulate_device(pose); every set sees the same noise realisation (row 0 of rr_set_noise_offsets). */
+ * by rr_simulate_device(pose); every set sees the same noise realisation (row 0 of rr_set_noise_offsets).  One
+ * difference in ERROR behaviour: with max_waves_per_azimuth left at 0 the queues of a batch are sized for its largest
+ * number of passes (and a lane that already holds larger ones is reused as it is), so a set that alone would have run
+ * into the 65,536-wave clamp of its own nominal capacity (n_samples x 2^(passes-1) beyond 65,536) may render completely
+ * here where the one-by-one call returns -7; a user-set max_waves_per_azimuth is honoured exactly. */
 typedef struct rr_param_set {
     const rr_material* materials;
     const float* beam_dirs;
@@ -391,7 +395,10 @@ int rr_multi_simulate_batch(rr_multi* m, const float* poses, int n_frames, uint8
  * overlaps the collective, the transpose and the D2H copy of batch k; a call that finds its slot still busy waits for
  * that older batch first.  h_imgs_u8 should be page-locked (rr_host_alloc) and handed out from a ring at least as deep
  * as the slots; it must stay valid and unread until waited for.  After any error return nothing of the object is in
- * flight any more (every device drained, error bits cleared): the caller may free its buffers.
+ * flight any more (every device drained, error bits cleared): the caller may free its buffers.  AN ERROR INVALIDATES EVERY
+ * BATCH IN FLIGHT: error bits are kept per frame lane, not per batch, and the drain reads and clears them all, so the other
+ * batches that were in flight report the same code from the rr_multi_wait for their own buffer (or from the call that next
+ * uses their slot), whatever their images look like; rr_multi_wait(m, NULL) reports the error once for all of them.
  * With ONE device a batch takes rr_simulate_batch_host_async's route (deferred, trickled host copy). */
 int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames, uint8_t* h_imgs_u8);
 int rr_multi_wait(rr_multi* m, const void* h_imgs_u8);

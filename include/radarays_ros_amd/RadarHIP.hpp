@@ -184,7 +184,8 @@ public:
     // The same action with the optimiser's WHOLE parameter vector (scripts/radaray_opti.py:36-113: model.beam_width,
     // model.n_reflections, the material values): one RadarParams per evaluation, one call for all of them
     // (rr_simulate_param_sets: sets with the same beam_width share pass 0, sets with fewer passes stop early).  The beam of
-    // a set is drawn like push() draws it -- same seed for every set, so equal widths give equal directions;
+    // a set is drawn like push() draws it -- with the very seed push() used for the current beam, so equal widths give equal
+    // directions and sets that differ only in beam_width share their variates;
     // model.n_samples must be the current one.  `real` given: the objective values of radaray_opti.py:196 come back
     // (PSNR against the real image, skimage's formula; the optimiser minimises its negative) and, with want_images false,
     // no image leaves the GPU.
@@ -199,7 +200,7 @@ public:
         std::vector<rr_material> flat; flat.reserve(sets.size() * n_mat);
         std::vector<std::vector<float>> dirs(sets.size());
         std::vector<rr_param_set> ps(sets.size());
-        const uint32_t seed = m_have_seed ? m_beam_seed : (uint32_t)std::random_device{}();
+        const uint32_t seed = m_beam_seed;     // the seed push() drew the CURRENT beam with: sets that differ only in beam_width see the same variates
         for (size_t k = 0; k < sets.size(); k++) {
             const RadarParams& p = sets[k];
             if (p.materials.size() != n_mat || p.model.n_samples != nb) { m_err = "every parameter set needs the loaded number of materials and the current n_samples"; return false; }
@@ -237,7 +238,11 @@ private:
         if (m_resample || m_waves_start.empty()) {    // RadarCPU.cpp:136-145
             const size_t n = m_params.model.n_samples;
             m_waves_start.assign(3 * n, 0.0f);
-            const uint32_t seed = m_have_seed ? m_beam_seed : (uint32_t)std::random_device{}();
+            // the reference seeds every re-draw from std::random_device (radar_algorithms.cpp:258-259); so does this, unless
+            // setBeamSeed fixed one -- and the seed that was USED is kept, so that a parameter batch can repeat the draw for
+            // other beam widths on the same variates (advisor, round 4)
+            if (!m_have_seed) m_beam_seed = (uint32_t)std::random_device{}();
+            const uint32_t seed = m_beam_seed;
             if (rr_sample_cone_local(seed, m_params.model.beam_width, n, m_cfg.beam_sample_dist,
                                      (float)m_cfg.beam_sample_dist_normal_p_in_cone, m_waves_start.data())) {
                 m_err = "sample_cone_local: beam_sample_dist must be 0..3"; std::cout << "[RadarHIP] " << m_err << std::endl; return false;

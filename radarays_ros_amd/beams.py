@@ -97,6 +97,11 @@ def cone_dirs(width_rad, sample_dist, p_in_cone, u_angle, r_variate):
 
 def sample_cone_local(beam_width_deg, n_samples, sample_dist=2, p_in_cone=0.8, seed=42):
     """m_waves_start directions for RadarModelConfig.beam_width (degrees)."""
-    width = np.float32(beam_width_deg * np.pi / 180.0)   # Radar.cpp:213
+    return sample_cone_local_rad(np.float32(beam_width_deg * np.pi / 180.0), n_samples, sample_dist, p_in_cone, seed)   # Radar.cpp:213
+
+
+def sample_cone_local_rad(width_rad, n_samples, sample_dist=2, p_in_cone=0.8, seed=42):
+    """The same for RadarModel.beam_width (radians, f32: msg/RadarModel.msg) -- what rr_sample_cone_local takes.  A width that
+    went through degrees and back can differ by an ulp from the one the C++ twin passes (advisor, round 4)."""
     u, r = variates(n_samples, sample_dist, seed)
-    return cone_dirs(width, sample_dist, p_in_cone, u, r)
+    return cone_dirs(np.float32(width_rad), sample_dist, p_in_cone, u, r)

@@ -1355,7 +1355,13 @@ int rr_simulate_param_sets_device(rr_ctx* c, const float pose[7], const rr_param
         rc = run_frame(c, L, pose, 0, g0.n_angles, nullptr, nullptr, s, n_sets, L.d_matsets.p, (int)n_mat, false, nullptr, nullptr, 0, &plan);
     }
     c->passes_override = -1;
-    if (rc) return rc;
+    if (rc) {
+        // staged copies from the lane's host vectors may already be enqueued (advisor, round 4): the next call on this lane
+        // must not rewrite them underneath -- it waits for ev_consumed like after a complete batch
+        (void)hipEventRecord(L.ev_consumed, s);
+        L.pending_consume = true;
+        return rc;
+    }
     { TimedScope t(c, s, "assemble");
       launch_assemble_u8(L.d_cols_u8.p, d_imgs_u8, g0.n_angles, g0.n_cells, g0.scroll_image, s, g0.n_angles,
                          (size_t)g0.n_angles * g0.n_cells, n_sets, (size_t)g0.n_angles * g0.n_cells); }

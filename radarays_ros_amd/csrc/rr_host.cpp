@@ -145,9 +145,16 @@ bool ply_read(std::istream& f, const std::string& t, bool big, double& out)
     return true;
 }
 
-void fan(const std::vector<long long>& idx, std::vector<uint32_t>& faces)
+// a vertex index read as a double (PLY) -> long long: only a finite value inside [0, 2^32) is an index; anything else becomes
+// -1, which fan() refuses (casting NaN / inf to an integer is undefined, and a value above 2^32 would wrap to a valid index)
+inline long long index_of(double v) { return (std::isfinite(v) && v >= 0.0 && v < 4294967296.0) ? (long long)v : -1; }
+
+// false: an index outside [0, 2^32) (advisor, round 4)
+bool fan(const std::vector<long long>& idx, std::vector<uint32_t>& faces)
 {
+    for (long long i : idx) if (i < 0 || i > 0xFFFFFFFFll) return false;
     for (size_t k = 1; k + 1 < idx.size(); k++) { faces.push_back((uint32_t)idx[0]); faces.push_back((uint32_t)idx[k]); faces.push_back((uint32_t)idx[k + 1]); }
+    return true;
 }
 
 bool load_ply(const std::string& path, std::vector<float>& verts, std::vector<uint32_t>& faces, std::string& err)
@@ -185,11 +192,15 @@ bool load_ply(const std::string& path, std::vector<float>& verts, std::vector<ui
             if (e.props[k].list) continue;
             if (e.props[k].name == "x") ix = (int)k; else if (e.props[k].name == "y") iy = (int)k; else if (e.props[k].name == "z") iz = (int)k;
         }
+        // no element count of the header is trusted beyond the file: a row with properties takes at least a byte, and an
+        // element WITHOUT properties reads nothing, so nothing would ever fail at EOF (`element foo 18446744073709551615`
+        // spun for 2^64 rows: advisor, round 4)
+        if (e.count > file_bytes) { err = path + ": element '" + e.name + "': count exceeds the file"; return false; }
         if (is_v) {
             if (ix < 0 || iy < 0 || iz < 0) { err = path + ": vertex element without x / y / z"; return false; }
-            if (e.count > file_bytes) { err = path + ": vertex count exceeds the file"; return false; }     // (an element takes at least a byte)
             verts.reserve(3 * e.count); have_verts = true;
         }
+        if (e.props.empty()) continue;
         std::vector<long long> idx;
         for (size_t r = 0; r < e.count; r++) {
             float xyz[3] = { 0, 0, 0 };
@@ -211,9 +222,9 @@ bool load_ply(const std::string& path, std::vector<float>& verts, std::vector<ui
                         double v = 0.0;
                         if (ascii) { if (!(f >> v)) { err = path + ": truncated PLY body"; return false; } }
                         else if (!ply_read(f, p.type, big, v)) { err = path + ": truncated PLY body"; return false; }
-                        if (want) idx.push_back((long long)v);
+                        if (want) idx.push_back(index_of(v));
                     }
-                    if (want) fan(idx, faces);
+                    if (want && !fan(idx, faces)) { err = path + ": face index outside [0, 2^32)"; return false; }
                 }
             }
             if (is_v) { verts.push_back(xyz[0]); verts.push_back(xyz[1]); verts.push_back(xyz[2]); }
@@ -251,7 +262,7 @@ bool load_obj(const std::string& path, std::vector<float>& verts, std::vector<ui
             }
             if (idx.size() < 3) continue;
             const size_t before = faces.size() / 3;
-            fan(idx, faces);
+            if (!fan(idx, faces)) { err = path + ": face index before the first vertex"; return false; }
             for (size_t k = before; k < faces.size() / 3; k++) obj.push_back((uint32_t)(cur > 0 ? cur : 0));
         }
     }

@@ -129,6 +129,7 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
     while (true) {
         // ---- ONE batch of loads per step, whatever the step is (single s_waitcnt) ----
         const bool leaf = (cur & kLeafFlag) != 0;
+        if (STATS) n_tris += 0x10000u;   // high half: loop iterations of this lane = its traversal steps, node steps that descend included (advisor, round 4: counted at the pop only, a tree with more interior descents was scored as cheaper)
         if (STATS && wstat) {   // wave-level shape of this iteration (same value in every live lane)
             wstat[0]++; wstat[1] += __ballot(!leaf) != 0ull; wstat[2] += __ballot(leaf) != 0ull;
             wstat[3] += (unsigned)__builtin_popcountll(__ballot(true)) >> 2;
@@ -226,7 +227,6 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
             }
         }
         // pop
-        if (STATS) n_tris += 0x10000u;   // high half: loop iterations of this lane
         if (!CULL) {
             if (sp == 0) break;
             sp--;

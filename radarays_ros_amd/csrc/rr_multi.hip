@@ -88,6 +88,9 @@ struct MultiSlot {
     uint32_t* h_bits = nullptr;           // page-locked [n_devices]: rr_peek_error_bits_async
     const void* dst = nullptr;            // the caller's buffer of the batch in flight
     bool pending = false;
+    int failed = 0;                       // != 0: this batch was in flight when another one's error drained the object -- its
+                                          // images are not to be trusted (error bits are per frame lane, not per batch, and a
+                                          // drain reads and clears them all); reported by the wait for its buffer / the next use of the slot
     bool owns_streams = true;             // one device: twice as many records as streams (see rr_create_multi)
 };
 
@@ -346,7 +349,10 @@ namespace {
 // after an error: nothing of this object may still be in flight when the caller gets the code back (a late D2H copy
 // into a buffer the caller frees on error; sticky error bits that would fail the next, healthy call) -- every device is
 // drained, its error bits are read and cleared, every slot is free again.  Returns the first error a device reports.
-int drain_all(rr_multi* m, std::string* first_msg)
+// An error invalidates EVERY batch in flight (advisor, round 4): the drain reads and clears the sticky bits of all frame
+// lanes, so a second overflowing batch could no longer be told from a healthy one -- the other pending slots are marked
+// failed with `code` and report it from their own rr_multi_wait / the next use of their slot.
+int drain_all(rr_multi* m, std::string* first_msg, const MultiSlot* culprit = nullptr, int code = 0)
 {
     int first = 0;
     for (size_t i = 0; i < m->ctx.size(); i++) { (void)hipSetDevice(m->devices[i]); (void)hipDeviceSynchronize(); }
@@ -354,19 +360,30 @@ int drain_all(rr_multi* m, std::string* first_msg)
         const int rc = rr_synchronize(m->ctx[i], nullptr);
         if (rc && !first) { first = rc; if (first_msg) *first_msg = std::string("device ") + std::to_string(m->devices[i]) + ": " + rr_last_error(m->ctx[i]); }
     }
-    for (MultiSlot& S : m->slots) { S.pending = false; S.dst = nullptr; for (size_t i = 0; i < m->ctx.size(); i++) S.h_bits[i] = 0; }
+    if (!code) code = first ? first : -7;
+    for (MultiSlot& S : m->slots) {
+        if (S.pending && &S != culprit) S.failed = code;        // keeps its dst: the wait for that buffer reports it
+        else if (!S.failed) S.dst = nullptr;
+        S.pending = false;
+        for (size_t i = 0; i < m->ctx.size(); i++) S.h_bits[i] = 0;
+    }
     return first;
 }
 
 // a launch-time failure: keep ITS message, but hand the object back drained
 int fail_drained(rr_multi* m, int code, const std::string& msg)
 {
-    (void)drain_all(m, nullptr);
+    (void)drain_all(m, nullptr, nullptr, code);
     return mfail(m, code, msg);
 }
 
 int wait_slot(rr_multi* m, MultiSlot& S)
 {
+    if (S.failed) {
+        const int rc = S.failed;
+        S.failed = 0; S.dst = nullptr;
+        return mfail(m, rc, "this batch was in flight when another batch's error drained the object: its images are invalid (an error invalidates every batch in flight)");
+    }
     if (!S.pending) return 0;
     const int n = (int)m->ctx.size();
     hipError_t e = hipSetDevice(m->devices[0]);
@@ -382,8 +399,9 @@ int wait_slot(rr_multi* m, MultiSlot& S)
     for (int i = 0; i < n; i++) bits |= S.h_bits[i];
     if (bits) {
         std::string msg;
-        const int rc = drain_all(m, &msg);
-        return mfail(m, rc ? rc : ((bits & 1u) ? -7 : -8), rc ? msg : "a device reported an overflow / bad id");
+        const int code = (bits & 1u) ? -7 : -8;
+        const int rc = drain_all(m, &msg, &S, code);
+        return mfail(m, rc ? rc : code, rc ? msg : "a device reported an overflow / bad id");
     }
     return 0;
 }
@@ -397,10 +415,12 @@ int rr_multi_wait(rr_multi* m, const void* h_imgs_u8)
     int first = 0;
     for (size_t k = 0; k < m->slots.size(); k++) {
         MultiSlot& S = m->slots[(m->next_slot + k) % m->slots.size()];
-        if (!S.pending || (h_imgs_u8 && S.dst != h_imgs_u8)) continue;
+        if ((!S.pending && !S.failed) || (h_imgs_u8 && S.dst != h_imgs_u8)) continue;
         const int rc = wait_slot(m, S);
         if (rc) { if (!first) first = rc; break; }       // (a failed wait drained everything)
     }
+    // "every outstanding batch": the error is reported once for all of them
+    if (!h_imgs_u8 && first) for (MultiSlot& S : m->slots) if (S.failed) { S.failed = 0; S.dst = nullptr; }
     return first;
 }
 

@@ -121,8 +121,8 @@ class RadarHIP:
             self._ctx.set_materials(self.m_params.materials, self.m_object_materials, self.m_material_id_air)
             self._dirty_mat = False
         if self.m_resample:     # RadarCPU.cpp:136-145
-            self.m_waves_start = beams.sample_cone_local(
-                self.m_cfg.beam_width, self.m_params.model.n_samples, self.m_cfg.beam_sample_dist,
+            self.m_waves_start = beams.sample_cone_local_rad(     # model.beam_width: radians, what the C++ twin passes
+                self.m_params.model.beam_width, self.m_params.model.n_samples, self.m_cfg.beam_sample_dist,
                 self.m_cfg.beam_sample_dist_normal_p_in_cone, seed=self._beam_seed)
             self._ctx.set_beam_samples(self.m_waves_start)
             self.m_resample = False
@@ -172,8 +172,8 @@ class RadarHIP:
                 raise ValueError("every parameter set needs %d materials and n_samples = %d" % (n_mat, nb))
             dirs = None
             if abs(p.model.beam_width - self.m_params.model.beam_width) > 1e-7:
-                dirs = beams.sample_cone_local(np.degrees(p.model.beam_width), nb, self.m_cfg.beam_sample_dist,
-                                               self.m_cfg.beam_sample_dist_normal_p_in_cone, seed=self._beam_seed)
+                dirs = beams.sample_cone_local_rad(p.model.beam_width, nb, self.m_cfg.beam_sample_dist,
+                                                   self.m_cfg.beam_sample_dist_normal_p_in_cone, seed=self._beam_seed)
             ps.append({"materials": [m.astuple() for m in p.materials], "beam_dirs": dirs, "n_reflections": int(p.model.n_reflections)})
         imgs, psnr = self._ctx.simulate_param_sets(self.Tsm_last, ps, n_mat, ref_u8=real, want_images=want_images)
         msgs = None if imgs is None else [

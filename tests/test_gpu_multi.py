@@ -137,6 +137,22 @@ def test_multi_async_error_is_reported_once_and_drains(native_lib, small, monkey
     m.simulate_batch_async(good, h[2].ptr)
     m.wait(h[2].ptr)
     assert np.array_equal(h[2].array, ref)
+    # an error invalidates every batch in flight: the drain reads and clears ALL lanes' error bits, so the
+    # batches in flight beside the failing one report the error from the wait for their own buffers -- never a silent success
+    m.simulate_batch_async(good, h[0].ptr)
+    m.set_config(cfg, 400, max_waves_per_azimuth=61)
+    m.simulate_batch_async(good, h[1].ptr)                     # overflows
+    m.simulate_batch_async(good, h[2].ptr)                     # overflows too; its bits would be cleared by the drain
+    m.wait(h[0].ptr)                                           # the healthy batch, waited for first: fine
+    with pytest.raises(native_lib.RRError, match="capacity exceeded|overflow"):
+        m.wait(h[1].ptr)
+    with pytest.raises(native_lib.RRError, match="invalidates every batch in flight"):
+        m.wait(h[2].ptr)
+    m.wait(h[2].ptr); m.wait(None)                             # each reported once
+    m.set_config(cfg, 400)
+    m.simulate_batch_async(good, h[2].ptr)
+    m.wait(None)
+    assert np.array_equal(h[2].array, ref)
     assert np.array_equal(m.simulate_batch(good), ref)
     for x in h:
         x.close()

@@ -88,6 +88,30 @@ def test_rr_load_mesh_file_errors(tmp_path):
                  "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 7\n")
     with pytest.raises(native.RRError, match="out of range"):
         native.load_mesh_file(t)
+    # advisor, round 4: an element without properties and an absurd count reads nothing per row, so nothing failed at EOF
+    # and the row loop spun for 2^64 iterations; every element's count is now checked against the file size
+    import time
+    head = "ply\nformat ascii 1.0\nelement foo 18446744073709551615\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+    t.write_text(head + "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    t0 = time.time()
+    with pytest.raises(native.RRError, match="element 'foo': count exceeds the file"):
+        native.load_mesh_file(t)
+    assert time.time() - t0 < 5.0
+    # ... an empty element with a sane count is simply skipped
+    t.write_text(head.replace("18446744073709551615", "7") + "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    assert native.load_mesh_file(t)["faces"].tolist() == [[0, 1, 2]]
+    # an index that is not a number in [0, 2^32): NaN / inf (casting them is undefined), negative, or large enough to wrap
+    import struct
+    for bad in (float("nan"), float("inf"), -1.0, 4294967296.0 + 1.0):
+        body = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<B3d", 3, 0.0, 1.0, bad)
+        t.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                      b"element face 1\nproperty list uchar double vertex_indices\nend_header\n" + body)
+        with pytest.raises(native.RRError, match="face index outside"):
+            native.load_mesh_file(t)
+    o = tmp_path / "neg.obj"
+    o.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -9\n")
+    with pytest.raises(native.RRError, match="before the first vertex"):
+        native.load_mesh_file(o)
 
 
 DAE_RICH = """<?xml version="1.0" encoding="utf-8"?>
