@@ -338,6 +338,14 @@ int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* 
  *   out_hist[p]  the largest per-segment wave count seen in pass p since mesh / materials / beam / config last changed
  *   *repaired_groups  16-ray groups the repair launches had to trace since then (0 once the history has settled) */
 int rr_get_trace_grid(rr_ctx* ctx, uint32_t out_rows[24], uint32_t out_hist[24], uint64_t* repaired_groups);
+/* Launch graphs (round 5): the launch chain of a pose batch (rr_simulate_batch_*_device, rr_simulate_columns_device,
+ * rr_multi's device entries) that has been issued before with the same shape -- azimuth block, frames, output buffer,
+ * trace rows -- is captured in a hipGraph on its second use and replayed from then on: one hipGraphLaunch instead of
+ * 4..20 kernel launches (host time per chain 46 -> ~11 us at 4 passes); the poses of a replay travel as the parameters of the
+ * graph's first node.  Chains that carry a host copy, parameter batches and instrumented runs (timing / statistics /
+ * roctx) are issued kernel by kernel.  Any setter, mesh change or buffer reallocation drops the captured graphs.
+ * Returns how many chains this context has captured / replayed. */
+int rr_get_graph_stats(rr_ctx* ctx, uint64_t* captures, uint64_t* replays);
 /* average duration (ms) of the trace kernel launches since the last call with
  * reset!=0, measured with hipEvents on the launch stream when timing mode is
  * on; also returns the number of launches.  Used by bench.py for roofline. */
@@ -441,6 +449,7 @@ void rr_free_mesh(rr_mesh* m);
  * RR_COPY_BLOCKS (8)      one-wave workgroups of a trace launch that trickle a deferred host copy; 0: never fold
  * RR_FOLD_MIN_BUSY (2)    other lanes that must be busy for a host copy to be folded into the next batch
  * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)
+ * RR_GRAPHS (1)           launch chains of pose batches captured and replayed as hipGraphs (rr_get_graph_stats); 0: kernel by kernel
  * RR_TIGHT_GRID (1)       later-pass trace rows sized by the history of earlier batches (rr_get_trace_grid); 0: the doubling bound
  * RR_TIGHT_FORCE (0)      n > 0: rows of n workgroups whatever the history says (tests: nearly every ray goes through the repair launch)
  * RR_STACK_LDS (64)       traversal stack entries kept in LDS (lower: exercises the HBM spill path)

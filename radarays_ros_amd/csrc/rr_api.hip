@@ -31,6 +31,8 @@ void launch_debug_trace(const Params& P, const float* origs, const float* dirs, 
                         float* out_t, uint32_t* out_face, hipStream_t s, unsigned long long* steps = nullptr);
 void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s, size_t n_tris);
 void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s);
+void launch_set_poses(const PoseArgs& a, float* table, hipStream_t s);
+void* set_poses_kernel();
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
 }  // namespace rr
 
@@ -91,6 +93,16 @@ struct Lane {
     // and the page-locked copy of the history that arrives behind every batch (read without a fence: it is a hint)
     DevBuf<GridHint> d_hint; DevBuf<uint32_t> d_ovf_list; int ovf_stride = 0;
     uint32_t* h_hist = nullptr; int hist_gen = 0;
+    // Launch graphs (round 5): the launch chain of a batch -- pose upload, n_reflections x {trace [+ repair], shade, scan},
+    // column, history copy -- captured once per (azimuth block, frames, output buffer, trace rows) and replayed with ONE
+    // hipGraphLaunch; the poses are the only thing that changes between replays (k_set_poses' parameters).  Host time per
+    // chain: 46 us launched kernel by kernel (16 launches) against ~11 us replayed (tools/cpp_bench.cpp graph)
+    struct FrameGraph {
+        int az_begin = 0, az_end = 0, n_frames = 0; const void* cols = nullptr; unsigned short rows[kMaxPasses] = {};
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; hipGraphNode_t pose_node = nullptr; uint64_t last_use = 0; int hits = 0;
+    };
+    std::vector<FrameGraph> graphs; int graph_gen = 0;
+    DevBuf<float> d_poses;       // [RR_MAX_BATCH][7]: Params::pose_table of the replayed launches
     unsigned short last_rows[kMaxPasses] = {};     // rows the lane's last batch was launched with (0: the bound)
 
     hipStream_t stream = nullptr;
@@ -181,6 +193,9 @@ struct rr_ctx {
     int tight_grid = 1;          // later-pass trace rows sized by what earlier batches needed (RR_TIGHT_GRID=0: the doubling bound)
     int tight_force = 0;         // RR_TIGHT_FORCE=n: rows of n workgroups whatever the history says (tests of the repair path)
     int hist_gen = 1;            // bumped whenever mesh / materials / beam / config change: the lanes' histories start over
+    int use_graphs = 1;          // RR_GRAPHS=0: every launch chain is issued kernel by kernel
+    int graph_gen = 1;           // bumped whenever anything a captured launch bakes in may have changed (tables, tree, lane buffers)
+    uint64_t graph_clock = 0, graph_replays = 0, graph_captures = 0;
 };
 
 namespace {
@@ -309,6 +324,7 @@ int upload_tables(rr_ctx* c)
     const rr_config& g = c->cfg;
     const unsigned dirty = c->tables_dirty;
     if (dirty & (rr_ctx::D_CFG | rr_ctx::D_BEAMS | rr_ctx::D_MAT)) c->hist_gen++;     // wave counts per pass change: the trace-grid history starts over
+    c->graph_gen++;            // captured launches hold table pointers and scalars of the old parameters
     if (dirty & rr_ctx::D_CFG) {
     // Tas.R = EulerAngles{0,0,theta(angle)} -> quaternion (rmagine ZYX), RadarCPU.cpp:202
     std::vector<float4> qas((size_t)g.n_angles);
@@ -397,6 +413,12 @@ int upload_tables(rr_ctx* c)
     return 0;
 }
 
+void drop_graphs(Lane& L)
+{
+    for (Lane::FrameGraph& fg : L.graphs) { if (fg.ge) (void)hipGraphExecDestroy(fg.ge); if (fg.g) (void)hipGraphDestroy(fg.g); }
+    L.graphs.clear();
+}
+
 int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
 {
     const rr_config g = eff_config(c);      // (a parameter batch may ask for more passes than the config)
@@ -443,6 +465,8 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     if (spill_depth > 0) RR_HIP(c, L.d_spill.ensure((size_t)spill_depth * threads));
     else RR_HIP(c, L.d_spill.ensure(1));
     L.buf_seg = n_seg; L.buf_cap = cap; L.buf_sigcap = sigcap; L.buf_cells = g.n_cells; L.buf_passes = std::max(1, g.n_reflections);
+    RR_HIP(c, L.d_poses.ensure((size_t)RR_MAX_BATCH * 7));
+    L.graph_gen = 0;           // the lane's buffers moved: its captured launches point at the old ones
     return 0;
 }
 
@@ -643,31 +667,105 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         }
     }
     std::memcpy(L.last_rows, P.tight_groups, sizeof(L.last_rows));
+    // the launch chain of the batch
+    auto enqueue = [&](Params& Q) -> int {
     for (int pass = 0; pass < g.n_reflections; pass++) {
         // the previous batch's images ride on the later-pass launches, one slice each (rr_simulate_batch_host_async)
-        P.copy_blocks = 0;
+        Q.copy_blocks = 0;
         if (pass >= 1 && copy_src) {
             const size_t n16 = copy_bytes / 16, slices = (size_t)g.n_reflections - 1, k = (size_t)pass - 1;
             const size_t b = n16 * k / slices, e = n16 * (k + 1) / slices;
-            P.copy_src = reinterpret_cast<const uint4*>(copy_src) + b; P.copy_dst = reinterpret_cast<uint4*>(copy_dst) + b;
-            P.copy_n16 = e - b; P.copy_blocks = c->copy_blocks;
+            Q.copy_src = reinterpret_cast<const uint4*>(copy_src) + b; Q.copy_dst = reinterpret_cast<uint4*>(copy_dst) + b;
+            Q.copy_n16 = e - b; Q.copy_blocks = c->copy_blocks;
         }
         if (c->roctx) roctx_push(pass == 0 ? "trace pass 0" : "trace");
         if (c->timing) {
             // the kernel's own begin/end timestamps (hipExtLaunchKernel events), on its launch stream
             hipEvent_t a = c->take_event(), b = c->take_event();
-            launch_trace(P, pass, c->stats_mode, s, a, b);
+            launch_trace(Q, pass, c->stats_mode, s, a, b);
             c->timers[pass == 0 ? "trace0" : "trace"].pending.emplace_back(a, b);
         } else {
-            launch_trace(P, pass, c->stats_mode, s);
+            launch_trace(Q, pass, c->stats_mode, s);
         }
         if (c->roctx) roctx_pop();
-        { TimedScope t(c, s, "shade"); launch_shade(P, pass, s); }
-        if (pass < g.n_reflections - 1) { TimedScope t(c, s, "scan"); launch_scan(P, pass, s); }
+        { TimedScope t(c, s, "shade"); launch_shade(Q, pass, s); }
+        if (pass < g.n_reflections - 1) { TimedScope t(c, s, "scan"); launch_scan(Q, pass, s); }
     }
-    { TimedScope t(c, s, "column"); launch_column(P, s); }
+    { TimedScope t(c, s, "column"); launch_column(Q, s); }
     // the history this batch leaves behind travels to the host behind it (96 B; read without a fence by later batches)
     if (c->tight_grid && g.n_reflections > 1) RR_HIP(c, hipMemcpyAsync(L.h_hist, L.d_hint.p->hist, kMaxPasses * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return 0;
+    };
+    // Launch graphs: a chain that has been issued before with the same shape is captured once and replayed -- one
+    // hipGraphLaunch instead of 4..20 launches (host time per device entry of rr_multi: 45-81 -> ~25 us).  Only plain pose
+    // batches: no carried host copy (its pointers move from call to call), no parameter batch, no timing / statistics /
+    // roctx instrumentation; whatever a captured launch bakes in is covered by graph_gen (tables, tree, lane buffers) or
+    // by the key (azimuth block, frames, output buffer, trace rows)
+    if (L.graph_gen != c->graph_gen) { drop_graphs(L); L.graph_gen = c->graph_gen; }
+    const bool graphable = c->use_graphs && !copy_src && !d_matsets && !c->timing && !c->stats_mode && !c->roctx && !d_cols_f32 && g.n_reflections > 0;
+    if (graphable) {
+        Lane::FrameGraph* fg = nullptr;
+        for (Lane::FrameGraph& x : L.graphs)
+            if (x.az_begin == az_begin && x.az_end == az_end && x.n_frames == n_frames && x.cols == (const void*)d_cols_u8 &&
+                std::memcmp(x.rows, P.tight_groups, sizeof(x.rows)) == 0) { fg = &x; break; }
+        if (!fg) {
+            if (L.graphs.size() >= 12) {           // forget the least recently used shape
+                size_t lru = 0;
+                for (size_t k = 1; k < L.graphs.size(); k++) if (L.graphs[k].last_use < L.graphs[lru].last_use) lru = k;
+                if (L.graphs[lru].ge) (void)hipGraphExecDestroy(L.graphs[lru].ge);
+                if (L.graphs[lru].g) (void)hipGraphDestroy(L.graphs[lru].g);
+                L.graphs.erase(L.graphs.begin() + (long)lru);
+            }
+            Lane::FrameGraph n;
+            n.az_begin = az_begin; n.az_end = az_end; n.n_frames = n_frames; n.cols = d_cols_u8;
+            std::memcpy(n.rows, P.tight_groups, sizeof(n.rows));
+            L.graphs.push_back(n);
+            fg = &L.graphs.back();
+        }
+        fg->last_use = ++c->graph_clock;
+        PoseArgs pa; std::memset(&pa, 0, sizeof(pa));
+        pa.n = n_frames;
+        for (int f = 0; f < n_frames; f++) for (int k = 0; k < 7; k++) pa.p[f][k] = pose[7 * f + k];
+        float* table = L.d_poses.p;
+        if (!fg->ge && fg->hits >= 1) {            // the second call with this shape: worth a capture
+            Params Q = P; Q.pose_table = table;
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                launch_set_poses(pa, table, s);
+                const int rcq = enqueue(Q);
+                hipGraph_t gph = nullptr;
+                e = hipStreamEndCapture(s, &gph);
+                if (rcq == 0 && e == hipSuccess && gph) {
+                    hipGraphExec_t ge = nullptr;
+                    if (hipGraphInstantiate(&ge, gph, nullptr, nullptr, 0) == hipSuccess) {
+                        size_t nn = 0; (void)hipGraphGetNodes(gph, nullptr, &nn);
+                        std::vector<hipGraphNode_t> nodes(nn); (void)hipGraphGetNodes(gph, nodes.data(), &nn);
+                        for (hipGraphNode_t nd : nodes) {
+                            hipGraphNodeType ty; hipKernelNodeParams kp{};
+                            if (hipGraphNodeGetType(nd, &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
+                                hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == set_poses_kernel()) { fg->pose_node = nd; break; }
+                        }
+                        if (fg->pose_node) { fg->g = gph; fg->ge = ge; c->graph_captures++; }
+                        else { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gph); }
+                    } else (void)hipGraphDestroy(gph);
+                } else if (gph) (void)hipGraphDestroy(gph);
+            }
+            (void)hipGetLastError();
+            if (!fg->ge) fg->hits = -1000000;      // capture is not available here: stay with plain launches for this shape
+        }
+        if (fg->ge) {
+            void* args[2] = { (void*)&pa, (void*)&table };
+            hipKernelNodeParams kp{};
+            kp.func = set_poses_kernel(); kp.gridDim = dim3(1); kp.blockDim = dim3(448); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
+            hipError_t e = hipGraphExecKernelNodeSetParams(fg->ge, fg->pose_node, &kp);
+            if (e == hipSuccess) e = hipGraphLaunch(fg->ge, s);
+            if (e != hipSuccess) return fail(c, -100, std::string("launch graph replay: ") + hipGetErrorString(e));
+            c->graph_replays++;
+            return 0;
+        }
+        fg->hits++;
+    }
+    { const int rcq = enqueue(P); if (rcq) return rcq; }
     RR_HIP(c, hipGetLastError());
     return 0;
 }
@@ -740,6 +838,7 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
     if (getenv("RR_CULL_POP")) c->cull_pop = atoi(getenv("RR_CULL_POP")) != 0;
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
+    if (getenv("RR_GRAPHS")) c->use_graphs = atoi(getenv("RR_GRAPHS")) != 0;
     if (getenv("RR_TIGHT_GRID")) c->tight_grid = atoi(getenv("RR_TIGHT_GRID")) != 0;
     if (getenv("RR_TIGHT_FORCE")) c->tight_force = std::max(0, atoi(getenv("RR_TIGHT_FORCE")));
     {   // the one angle of total reflection that does not depend on the material table
@@ -780,6 +879,7 @@ void rr_destroy(rr_ctx* c)
         L.d_hit.release(); L.d_sig_count.release(); L.d_spill.release(); L.d_cflag.release(); L.d_cols_u8.release();
         L.d_sigtmp.release(); L.d_sig.release(); L.d_cols_f32.release(); L.d_counters.release(); L.d_sticky.release(); L.d_seg_stats.release(); L.d_matsets.release(); L.d_matset_limits.release(); L.d_set_beams.release(); L.d_set_order.release(); L.d_set_order2.release(); L.d_img_u8.release(); L.d_img_f32.release();
         L.d_hint.release(); L.d_ovf_list.release(); if (L.h_hist) { (void)hipHostFree(L.h_hist); L.h_hist = nullptr; }
+        drop_graphs(L); L.d_poses.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
         for (Lane::CopyRec& r : L.rec) if (r.ev) (void)hipEventDestroy(r.ev);
@@ -828,7 +928,7 @@ int upload_tree(rr_ctx* c, const Bvh4& bvh)
     RR_HIP(c, hipDeviceSynchronize());
     c->n_nodes = nn; c->n_tris = nt;
     c->depth = bvh.depth; c->stack_need = bvh.stack_need;
-    c->have_mesh = true; c->hist_gen++;
+    c->have_mesh = true; c->hist_gen++; c->graph_gen++;
     for (Lane& L : c->lanes) L.buf_seg = 0;   // stack geometry may have changed
     return 0;
 }
@@ -963,7 +1063,7 @@ int rr_set_mesh_gpu(rr_ctx* c, const float* verts, size_t nv, const uint32_t* fa
     }
     c->n_nodes = nn; c->n_tris = nt; c->depth = depth; c->stack_need = need;
     c->hit_pad = guard_pad(verts, faces, nf);
-    c->have_mesh = true; c->hist_gen++;
+    c->have_mesh = true; c->hist_gen++; c->graph_gen++;
     for (Lane& L : c->lanes) L.buf_seg = 0;
     return 0;
 }
@@ -988,7 +1088,7 @@ int rr_copy_mesh(rr_ctx* c, rr_ctx* src)
     RR_HIP(c, hipDeviceSynchronize());
     c->tri_base4 = src->tri_base4; c->n_nodes = src->n_nodes; c->n_tris = src->n_tris;
     c->depth = src->depth; c->stack_need = src->stack_need; c->hit_pad = src->hit_pad;
-    c->have_mesh = true; c->hist_gen++;
+    c->have_mesh = true; c->hist_gen++; c->graph_gen++;
     return 0;
 }
 
@@ -1762,6 +1862,14 @@ int rr_get_trace_grid(rr_ctx* c, uint32_t out_rows[24], uint32_t out_hist[24], u
         for (int k = 0; k < kMaxPasses && out_hist; k++) out_hist[k] = std::max(out_hist[k], h.hist[k]);
     }
     if (repaired_groups) *repaired_groups = rep;
+    return 0;
+}
+
+int rr_get_graph_stats(rr_ctx* c, uint64_t* captures, uint64_t* replays)
+{
+    if (!c) return -1;
+    if (captures) *captures = c->graph_captures;
+    if (replays) *replays = c->graph_replays;
     return 0;
 }
 

@@ -151,6 +151,7 @@ struct Params {
     // frame f > 0 uses batch_poses[f - 1] (frame 0 uses q_sm / t_sm)
     int n_loc, n_frames;
     float batch_poses[63][7];     // RR_MAX_BATCH - 1 (kernel arguments: 1.8 KB of the 4 KB limit)
+    const float* pose_table;      // non-null: [n_frames][7] in device memory instead of q_sm / t_sm / batch_poses (replayed launch graphs)
     int n_beam, cap, sigcap;
     int n_cells, n_angles, n_materials, n_objects, material_id_air;
     int n_passes, record_multi_reflection, record_multi_path;
@@ -175,6 +176,8 @@ struct Params {
     int ovf_stride;
     unsigned short tight_groups[kMaxPasses];   // 16-ray workgroups per segment row of pass p; 0: the full doubling bound
 };
+
+struct PoseArgs { float p[64][7]; int n; };     // RR_MAX_BATCH poses by value (k_set_poses)
 
 __host__ __device__ inline int passes_of(const Params& P, int frame) { return P.set_mode ? (int)P.frame_passes[frame] : P.n_passes; }
 __host__ __device__ inline int beam_base(const Params& P, int frame) { return P.set_mode ? (int)P.frame_beam[frame] * P.n_beam : 0; }

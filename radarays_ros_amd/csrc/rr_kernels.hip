@@ -30,7 +30,10 @@ __device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t
     const int frame = seg / P.n_loc, az = P.az_begin + seg % P.n_loc;
     const Quat q_as = ld_quat(P.q_as + az);
     Quat q_sm = P.q_sm; V3 t_sm = P.t_sm;
-    if (frame > 0) {          // frame batch: one pose per frame, passed by value
+    if (P.pose_table) {       // replayed launch graph (run_frame): the poses of this call sit in the lane's table (k_set_poses)
+        const float* ps = P.pose_table + 7 * frame;
+        q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
+    } else if (frame > 0) {   // frame batch: one pose per frame, passed by value
         const float* ps = P.batch_poses[frame - 1];
         q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
     }
@@ -1432,6 +1435,19 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
         if (cull) hipLaunchKernelGGL((k_trace_repair<true>), rgrid, block, lds, s, Pl, pass);
         else      hipLaunchKernelGGL((k_trace_repair<false>), rgrid, block, lds, s, Pl, pass);
     }
+}
+
+// first node of a replayed launch graph: the call's poses, passed by value, into the lane's pose table -- the ONE node whose
+// parameters change from replay to replay (hipGraphExecKernelNodeSetParams)
+__global__ void k_set_poses(const PoseArgs a, float* table)
+{
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i < 7 * a.n) table[i] = a.p[i / 7][i % 7];
+}
+void* set_poses_kernel() { return (void*)k_set_poses; }
+void launch_set_poses(const PoseArgs& a, float* table, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_set_poses, dim3(1), dim3(448), 0, s, a, table);
 }
 
 void launch_shade(const Params& P, int pass, hipStream_t s)

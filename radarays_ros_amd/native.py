@@ -20,7 +20,7 @@ SYMBOLS = [
     "rr_simulate_batch_columns_carry_device",
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
-    "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_get_trace_grid", "rr_set_timing_mode",
+    "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_get_trace_grid", "rr_get_graph_stats", "rr_set_timing_mode",
     "rr_get_kernel_time", "rr_get_kernel_samples", "rr_reserve_timing_events",
     "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_partition", "rr_multi_plan",
     "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_ctx",
@@ -136,6 +136,7 @@ def lib():
     L.rr_get_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.rr_debug_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.rr_get_trace_grid.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
+    L.rr_get_graph_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rr_get_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rr_get_kernel_samples.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -470,6 +471,12 @@ class Context:
         rows = np.zeros(24, np.uint32); hist = np.zeros(24, np.uint32); rep = C.c_uint64()
         self._ck(self._L.rr_get_trace_grid(self._h, rows.ctypes.data, hist.ctypes.data, C.byref(rep)))
         return rows, hist, int(rep.value)
+
+    def graph_stats(self):
+        """rr_get_graph_stats -> (launch chains captured, replayed)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.rr_get_graph_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def bvh_info(self):
         a, b, d, s = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()

@@ -336,3 +336,82 @@ def test_tight_trace_rows_follow_the_history_and_never_change_an_image(native_li
     g8, _, st = c1.simulate(busy[0])                                       # the synchronous entry point takes the same route
     assert np.array_equal(g8, want_busy[0]) and st["overflow"] == 0
     c1.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Launch graphs (rr_get_graph_stats): a replayed chain renders the same bytes as the chain issued kernel by kernel
+# ---------------------------------------------------------------------------------------------------------------------
+def test_launch_graphs_replay_identical_images_and_are_dropped_on_any_change(native_lib, monkeypatch):
+    """A pose batch issued a second time with the same shape is captured in a hipGraph, later calls replay it with new
+    poses (the parameters of the graph's first node): every image equals the kernel-by-kernel render (RR_GRAPHS=0).
+    A change of materials / config / beam / mesh drops the graphs (captured launches hold the old tables), a different
+    azimuth block or frame count is its own graph, instrumented runs are never replayed."""
+    import torch
+    s = gen.two_room_scene()
+    cfg = params.kaist_preset(n_reflections=3, ambient_noise=2)
+    mats = params.kaist_materials() + [params.PENETRABLE]
+    noise = (np.random.RandomState(3).uniform(0, 1, (4, 400)) * 1000.0).astype(np.float32)
+    poses = scenes.trajectory(12, "box12")
+    batches = [poses[0:4], poses[4:8], poses[8:12], poses[2:6], poses[5:9]]
+
+    def ctx():
+        c = native_lib.Context(0)
+        c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+        c.set_materials(mats, s["object_materials"], 0)
+        c.set_config(cfg)
+        c.set_beam_samples(golden_beams(32))
+        c.set_noise_offsets(noise)
+        return c
+    monkeypatch.setenv("RR_GRAPHS", "0")
+    monkeypatch.setenv("RR_LANES", "1")          # one frame lane: every batch meets the same buffers (and the same graph)
+    c0 = ctx()
+    want = [_batch(c0, b, cfg) for b in batches]
+    assert c0.graph_stats() == (0, 0)
+    monkeypatch.delenv("RR_GRAPHS")
+    c = ctx()
+    imgs = torch.zeros((4, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(b):
+        c.simulate_batch_device(b, imgs.data_ptr(), st)
+        c.synchronize(st)
+        return imgs.cpu().numpy()
+    for rep in range(3):
+        for k, b in enumerate(batches):
+            assert np.array_equal(run(b), want[k]), (rep, k)
+    cap, rep = c.graph_stats()
+    assert cap >= 1 and rep >= 10, (cap, rep)                      # (trace rows settle within the first calls: a few captures)
+    # other shapes are other graphs; the first use of a shape is never a replay
+    cols = torch.zeros((4, 100, cfg.n_cells), dtype=torch.uint8, device="cuda:0")
+    for _ in range(3):
+        c.simulate_batch_columns_device(batches[0], 100, 200, cols.data_ptr(), st)
+        c.synchronize(st)
+        assert np.array_equal(np.transpose(cols.cpu().numpy(), (0, 2, 1)), want[0][:, :, 100:200])
+    one = torch.zeros((1, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+    for _ in range(3):
+        c.simulate_batch_device(batches[1][:1], one.data_ptr(), st); c.synchronize(st)
+        assert np.array_equal(one.cpu().numpy()[0], want[1][0])
+    cap2, rep2 = c.graph_stats()
+    assert cap2 >= cap + 2 and rep2 >= rep + 2
+    # a change of the materials drops what was captured: same poses, other image, equal to a fresh kernel-by-kernel render
+    other = [mats[0], mats[1], params.RadarMaterial(0.2, 0.5, 0.4, 5.0)]
+    c.set_materials(other, s["object_materials"], 0)
+    c0.set_materials(other, s["object_materials"], 0)
+    want_other = _batch(c0, batches[0], cfg)
+    for _ in range(3):
+        assert np.array_equal(run(batches[0]), want_other)
+    assert not np.array_equal(want_other, want[0]) and c.graph_stats()[0] > cap2
+    # instrumented runs are issued kernel by kernel
+    c.set_timing_mode(1)
+    before = c.graph_stats()
+    for _ in range(3):
+        assert np.array_equal(run(batches[0]), want_other)
+    assert c.graph_stats() == before
+    c.set_timing_mode(0)
+    # an overflow inside a replayed chain is still reported
+    c.set_config(cfg, 400, max_waves_per_azimuth=33)
+    for k in range(3):
+        c.simulate_batch_device(batches[0], imgs.data_ptr(), st)
+        with pytest.raises(native_lib.RRError, match="capacity"):
+            c.synchronize(st)
+    c.close(); c0.close()

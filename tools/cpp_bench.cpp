@@ -88,6 +88,35 @@ int main(int argc, char** argv)
         for (int k = 0; k < frames; k++) { auto a = clk::now(); hipGraphLaunch(ge, gs); hipStreamSynchronize(gs); ts.push_back(secs(a, clk::now())); }
         std::sort(ts.begin(), ts.end());
         std::printf("hipGraph (%zu nodes): median %.3f ms per frame (p10 %.3f)\n", nn, 1e3 * ts[ts.size() / 2], 1e3 * ts[ts.size() / 10]);
+        // HOST time of the two ways to enqueue the chain (what a graph can save for a caller that issues many chains: rr_multi)
+        {
+            const int burst = 8;
+            double t_k = 0.0, t_g = 0.0, t_s = 0.0;
+            for (int rep = 0; rep < 40; rep++) {
+                hipStreamSynchronize(gs);
+                auto a = clk::now();
+                for (int k = 0; k < burst; k++) CK(rr_simulate_device(c, &poses[0], d_img, gs));
+                t_k += secs(a, clk::now());
+                hipStreamSynchronize(gs);
+                a = clk::now();
+                for (int k = 0; k < burst; k++) hipGraphLaunch(ge, gs);
+                t_g += secs(a, clk::now());
+            }
+            // one kernel node's parameters replaced before every launch (how a replay would get its poses)
+            std::vector<hipGraphNode_t> nodes(nn); hipGraphGetNodes(g, nodes.data(), &nn);
+            hipGraphNode_t kn = nullptr; hipKernelNodeParams kp{};
+            for (auto nd : nodes) { hipGraphNodeType ty; hipGraphNodeGetType(nd, &ty); if (ty == hipGraphNodeTypeKernel) { kn = nd; break; } }
+            if (kn && hipGraphKernelNodeGetParams(kn, &kp) == hipSuccess) {
+                for (int rep = 0; rep < 40; rep++) {
+                    hipStreamSynchronize(gs);
+                    auto a = clk::now();
+                    for (int k = 0; k < burst; k++) hipGraphExecKernelNodeSetParams(ge, kn, &kp);
+                    t_s += secs(a, clk::now());
+                }
+            }
+            std::printf("host time to enqueue one chain: kernel by kernel %.1f us, hipGraphLaunch %.1f us, hipGraphExecKernelNodeSetParams %.1f us per node\n",
+                        1e6 * t_k / (40 * burst), 1e6 * t_g / (40 * burst), 1e6 * t_s / (40 * burst));
+        }
         rr_destroy(c); return 0;
     }
     if (mode == "multi") {
@@ -141,6 +170,23 @@ int main(int argc, char** argv)
         std::printf("rr_multi_simulate_batch_async over %d device entr%s, %d poses per call: %.0f images/s host-resident = %.1f %% of the ctx route; "
                     "host time per call %.1f us (%.1f us per frame)\n", ndev, ndev == 1 ? "y" : "ies", batch,
                     steps * batch / t_m, 100.0 * t_ctx / t_m, 1e6 * t_enq / steps, 1e6 * t_enq / steps / batch);
+        // the CPU cost of a call proper: bursts of as many calls as there are slots, issued onto a DRAINED object -- no call
+        // of a burst waits for a slot, so the time is what the host spends issuing the launches (the figure above is the
+        // period of the steady state, which contains the wait for the GPU as soon as the GPU is the slower side)
+        {
+            const int slots = getenv("RR_MULTI_SLOTS") ? std::max(1, std::min(8, atoi(getenv("RR_MULTI_SLOTS")))) : 4;
+            double t_cpu = 0.0; int n_calls = 0;
+            for (int rep = 0; rep < 50; rep++) {
+                MK(rr_multi_wait(m, nullptr));
+                auto q0 = clk::now();
+                for (int k = 0; k < slots; k++)
+                    if (rr_multi_simulate_batch_async(m, &poses[7 * (k % (32 - batch + 1))], batch, host[k % ring])) return 1;
+                t_cpu += secs(q0, clk::now()); n_calls += slots;
+            }
+            MK(rr_multi_wait(m, nullptr));
+            std::printf("host CPU time per call, slots free (bursts of %d onto a drained object): %.1f us = %.1f us per device entry\n",
+                        slots, 1e6 * t_cpu / n_calls, 1e6 * t_cpu / n_calls / ndev);
+        }
         rr_destroy_multi(m);
         for (auto h : host) rr_host_free(h);
         return 0;
