@@ -2,7 +2,6 @@
 
 #include <cv_bridge/cv_bridge.h>
 
-#include <radarays_ros/radar_algorithms.h>
 
 #include <cmath>
 #include <cstring>

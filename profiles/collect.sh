@@ -7,6 +7,7 @@ tag=${1:-r04}; shift
 OUT=$R/gpurun_out/profiles_$tag; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 ARGS="--steps 60 --warmup 5 --no-cpu-baseline --no-extras $@"
+export RR_GRAPHS=0   # (the timed loop carries host copies and is never replayed from a graph; this keeps the instrumentation batches kernel by kernel too)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -- python3 $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/ktrace.log
 cp $(find $OUT/ktrace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 # the same launches with ONE batch on the GPU at a time (one stream, one buffer set): what roofline.isolated divides by

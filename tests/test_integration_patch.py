@@ -243,3 +243,59 @@ def test_adapter_reads_only_what_the_reference_declares(tree):
     # the output contract of RadarCPU.cpp:555-561
     assert '"mono8"' in open(os.path.join(tree, "src", "radarays_ros", "RadarHIP.cpp")).read()
     assert "header.stamp = stamp" in cpp and "header.frame_id = m_sensor_frame" in cpp
+
+
+def _generated_headers(dst):
+    """What catkin would generate from the reference's own IDL, as plain structs: cfg/RadarModel.cfg -> RadarModelConfig.h,
+    msg/*.msg -> <Msg>.h (float32 -> float, uint32 -> uint32_t, T[] -> std::vector<T>, other message types by name)."""
+    inc = os.path.join(dst, "radarays_ros")
+    os.makedirs(inc, exist_ok=True)
+    ctype = {"double": "double", "int": "int", "bool": "bool", "str": "std::string"}
+    fields = re.findall(r'gen\.add\(\s*"(\w+)"\s*,\s*(\w+)_t', open(os.path.join(REF, "cfg", "RadarModel.cfg")).read())
+    with open(os.path.join(inc, "RadarModelConfig.h"), "w") as f:
+        f.write("#pragma once\n#include <string>\nnamespace radarays_ros {\nclass RadarModelConfig {\npublic:\n")
+        for name, t in fields:
+            f.write("    %s %s;\n" % (ctype[t], name))
+        f.write("};\n}\n")
+    prim = {"float32": "float", "float64": "double", "uint32": "uint32_t", "int32": "int32_t", "uint8": "uint8_t", "bool": "bool", "string": "std::string"}
+    for fn in sorted(os.listdir(os.path.join(REF, "msg"))):
+        name = fn[:-4]
+        lines = [l.split("#")[0].split() for l in open(os.path.join(REF, "msg", fn)).read().splitlines()]
+        lines = [l for l in lines if len(l) >= 2]
+        with open(os.path.join(inc, name + ".h"), "w") as f:
+            f.write("#pragma once\n#include <cstdint>\n#include <string>\n#include <vector>\n")
+            for t, _ in lines:
+                base = t.rstrip("[]")
+                if base not in prim:
+                    f.write("#include <radarays_ros/%s.h>\n" % base)
+            f.write("namespace radarays_ros {\nstruct %s {\n" % name)
+            for t, field in lines:
+                base = t.rstrip("[]")
+                c = prim.get(base, base)
+                f.write("    %s %s;\n" % ("std::vector<%s>" % c if t.endswith("[]") else c, field))
+            f.write("};\n}\n")
+
+
+@needs_ref
+def test_adapter_type_checks_against_the_reference_headers(tree, tmp_path):
+    """g++ -fsyntax-only on the ROS-typed adapter: the reference's own Radar.hpp / radar_types.h, the headers catkin would
+    generate derived from the reference's IDL at test time, and signature-only stand-ins for ROS / cv_bridge / rmagine
+    (tests/cpp/ros_stubs/README.md: type-check scaffolding, not a build of the reference, pins nothing).  Also checked:
+    the scaffolding is not vacuous -- a misspelt config field or a wrong rr_* arity fails to compile."""
+    import subprocess
+    gen_dir = str(tmp_path / "gen")
+    _generated_headers(gen_dir)
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wno-unused-variable", "-I", os.path.join(ROOT, "tests", "cpp", "ros_stubs"),
+            "-I", gen_dir, "-I", os.path.join(tree, "include"), "-I", os.path.join(ROOT, "include")]
+    src = os.path.join(tree, "src", "radarays_ros", "RadarHIP.cpp")
+    r = subprocess.run(base + [src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    text = open(src).read()
+    for bad, why in ((text.replace("m_cfg.signal_max", "m_cfg.signal_maximum", 1), "a config field that does not exist"),
+                     (text.replace("rr_multi_set_config(m_multi, &c)", "rr_multi_set_config(m_multi, &c, 1)", 1), "an rr_* call with one argument too many"),
+                     (text.replace("m.velocity", "m.speed", 1), "a message field that does not exist")):
+        assert bad != text
+        p = tmp_path / "bad.cpp"
+        p.write_text(bad)
+        rb = subprocess.run(base + [str(p)], capture_output=True, text=True)
+        assert rb.returncode != 0, why
