@@ -18,6 +18,7 @@ RR_FUZZ_SEEDS=50000:$((50000 + 3000 * k)) run python -m pytest tests/test_gpu_pa
 run python tools/soak.py $((6000 * k)) 4
 run python tools/soak_host.py $((600 * k)) 4
 run python tools/soak_multi.py $((400 * k)) 8 2
+run python tools/soak_multi.py $((120 * k)) 8 3
 run python tools/soak_multi.py $((150 * k)) 3 3
 RR_MULTI_THREADS=0 run python tools/soak_multi.py $((200 * k)) 5 2
 RR_TIGHT_FORCE=2 run python tests/fuzz/fuzz_batch.py $((200 * k)) 91
