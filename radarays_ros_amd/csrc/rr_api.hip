@@ -102,7 +102,7 @@ struct Lane {
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; hipGraphNode_t pose_node = nullptr; uint64_t last_use = 0; int hits = 0;
     };
     std::vector<FrameGraph> graphs; int graph_gen = 0;
-    DevBuf<float> d_poses;       // [RR_MAX_BATCH][7]: Params::pose_table of the replayed launches
+    DevBuf<float> d_poses;       // [RR_MAX_BATCH][8]: Params::pose_table of the replayed launches
     unsigned short last_rows[kMaxPasses] = {};     // rows the lane's last batch was launched with (0: the bound)
 
     hipStream_t stream = nullptr;
@@ -465,7 +465,7 @@ int ensure_frame_buffers(rr_ctx* c, Lane& L, int n_seg, bool want_f32)
     if (spill_depth > 0) RR_HIP(c, L.d_spill.ensure((size_t)spill_depth * threads));
     else RR_HIP(c, L.d_spill.ensure(1));
     L.buf_seg = n_seg; L.buf_cap = cap; L.buf_sigcap = sigcap; L.buf_cells = g.n_cells; L.buf_passes = std::max(1, g.n_reflections);
-    RR_HIP(c, L.d_poses.ensure((size_t)RR_MAX_BATCH * 7));
+    RR_HIP(c, L.d_poses.ensure((size_t)RR_MAX_BATCH * 8));
     L.graph_gen = 0;           // the lane's buffers moved: its captured launches point at the old ones
     return 0;
 }
@@ -630,8 +630,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         P.materials = d_matsets; P.mat_limits = L.d_matset_limits.p; P.mat_stride = mat_stride;
         P.set_mode = 1;
         P.noise_rows = 1;     // every set is the SAME frame under another parameter set: one noise realisation (row 0)
-        P.motion_rows = 1;    // ... and one sweep of the antenna (table 0)
-        for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[k];
+        P.motion_rows = 1;    // ... and one sweep of the antenna (table 0); every set the SAME pose: q_sm / t_sm (no pose table)
         SetPlan dflt;
         if (!plan) {          // material sets only: one beam, every frame the config's passes
             for (int f = 0; f < n_frames; f++) { dflt.frame_passes[f] = (unsigned char)g.n_reflections; dflt.frame_beam[f] = 0; }
@@ -642,8 +641,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         std::memcpy(P.frame_beam, plan->frame_beam, (size_t)n_frames);
         std::memcpy(P.group_frame, plan->group_frame, (size_t)plan->n_groups);
         if (plan->d_beams) { P.beams = plan->d_beams; P.beam_order = plan->d_order; P.beam_order2 = plan->d_order2; }
-    } else
-    for (int f = 1; f < n_frames; f++) for (int k = 0; k < 7; k++) P.batch_poses[f - 1][k] = pose[7 * f + k];
+    }
     if (c->stats_mode || g.n_reflections == 0) RR_HIP(c, hipMemsetAsync(L.d_counters.p, 0, sizeof(Counters), s));
     L.last_n_seg = n_seg; L.last_n_passes = g.n_reflections;
     // later-pass trace rows as long as earlier batches needed (rr_device.h: GridHint).  Not for the statistics build (the
@@ -701,8 +699,21 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     // batches: no carried host copy (its pointers move from call to call), no parameter batch, no timing / statistics /
     // roctx instrumentation; whatever a captured launch bakes in is covered by graph_gen (tables, tree, lane buffers) or
     // by the key (azimuth block, frames, output buffer, trace rows)
+    // a batch of poses travels through the lane's pose table (k_set_poses ahead of the chain); one frame / a parameter batch
+    // (every set the same pose) use q_sm / t_sm
+    const bool pose_batch = n_frames > 1 && !d_matsets;
+    PoseArgs pa;
+    float* table = L.d_poses.p;
+    if (!d_matsets) {
+        std::memset(&pa, 0, sizeof(pa));
+        pa.n = n_frames;
+        for (int f = 0; f < n_frames; f++) for (int k = 0; k < 7; k++) pa.p[f][k] = pose[7 * f + k];
+    }
+    if (pose_batch) P.pose_table = reinterpret_cast<const float4*>(table);
     if (L.graph_gen != c->graph_gen) { drop_graphs(L); L.graph_gen = c->graph_gen; }
-    const bool graphable = c->use_graphs && !copy_src && !d_matsets && !c->timing && !c->stats_mode && !c->roctx && !d_cols_f32 && g.n_reflections > 0;
+    // (a single frame issued kernel by kernel keeps its pose by value -- no extra launch on the latency path; its REPLAYED chain
+    // reads the table like any other)
+    const bool graphable = !d_matsets && c->use_graphs && !copy_src && !c->timing && !c->stats_mode && !c->roctx && !d_cols_f32 && g.n_reflections > 0;
     if (graphable) {
         Lane::FrameGraph* fg = nullptr;
         for (Lane::FrameGraph& x : L.graphs)
@@ -723,12 +734,8 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
             fg = &L.graphs.back();
         }
         fg->last_use = ++c->graph_clock;
-        PoseArgs pa; std::memset(&pa, 0, sizeof(pa));
-        pa.n = n_frames;
-        for (int f = 0; f < n_frames; f++) for (int k = 0; k < 7; k++) pa.p[f][k] = pose[7 * f + k];
-        float* table = L.d_poses.p;
         if (!fg->ge && fg->hits >= 1) {            // the second call with this shape: worth a capture
-            Params Q = P; Q.pose_table = table;
+            Params Q = P; Q.pose_table = reinterpret_cast<const float4*>(table);
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 launch_set_poses(pa, table, s);
@@ -756,7 +763,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         if (fg->ge) {
             void* args[2] = { (void*)&pa, (void*)&table };
             hipKernelNodeParams kp{};
-            kp.func = set_poses_kernel(); kp.gridDim = dim3(1); kp.blockDim = dim3(448); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
+            kp.func = set_poses_kernel(); kp.gridDim = dim3(1); kp.blockDim = dim3(512); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
             hipError_t e = hipGraphExecKernelNodeSetParams(fg->ge, fg->pose_node, &kp);
             if (e == hipSuccess) e = hipGraphLaunch(fg->ge, s);
             if (e != hipSuccess) return fail(c, -100, std::string("launch graph replay: ") + hipGetErrorString(e));
@@ -765,6 +772,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         }
         fg->hits++;
     }
+    if (pose_batch) launch_set_poses(pa, table, s);
     { const int rcq = enqueue(P); if (rcq) return rcq; }
     RR_HIP(c, hipGetLastError());
     return 0;

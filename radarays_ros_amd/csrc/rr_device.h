@@ -147,11 +147,14 @@ struct Params {
     // scalars
     Quat q_sm; V3 t_sm;
     int az_begin, n_seg;
-    // frame batch: segment s belongs to frame s / n_loc and azimuth az_begin + s % n_loc;
-    // frame f > 0 uses batch_poses[f - 1] (frame 0 uses q_sm / t_sm)
+    // frame batch: segment s belongs to frame s / n_loc and azimuth az_begin + s % n_loc
     int n_loc, n_frames;
-    float batch_poses[63][7];     // RR_MAX_BATCH - 1 (kernel arguments: 1.8 KB of the 4 KB limit)
-    const float* pose_table;      // non-null: [n_frames][7] in device memory instead of q_sm / t_sm / batch_poses (replayed launch graphs)
+    // the poses of a batch: [n_frames][2] float4 = (q.xyzw)(t.xyz, 0) in the lane's device table, written by k_set_poses -- the
+    // first launch of the chain, whose by-value argument carries them (and the ONE node whose parameters change when the
+    // chain is replayed from a launch graph).  Null: every frame uses q_sm / t_sm (a single frame; a parameter batch).
+    // (Until round 5 the poses of frames 1..63 rode in Params itself: 1.8 KB of every kernel's arguments; a build that
+    // read them from EITHER place made the compiler copy all of Params into scratch -- 2.6 KB per lane, 7 waves per SIMD)
+    const float4* pose_table;
     int n_beam, cap, sigcap;
     int n_cells, n_angles, n_materials, n_objects, material_id_air;
     int n_passes, record_multi_reflection, record_multi_path;

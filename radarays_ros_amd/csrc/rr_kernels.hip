@@ -30,12 +30,12 @@ __device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t
     const int frame = seg / P.n_loc, az = P.az_begin + seg % P.n_loc;
     const Quat q_as = ld_quat(P.q_as + az);
     Quat q_sm = P.q_sm; V3 t_sm = P.t_sm;
-    if (P.pose_table) {       // replayed launch graph (run_frame): the poses of this call sit in the lane's table (k_set_poses)
-        const float* ps = P.pose_table + 7 * frame;
-        q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
-    } else if (frame > 0) {   // frame batch: one pose per frame, passed by value
-        const float* ps = P.batch_poses[frame - 1];
-        q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
+    // (the by-value pose is pinned in registers HERE: left as loads, the compiler sinks them below the branch as ONE load through
+    // a pointer that is either &P.q_sm or the table -- and keeps a private copy of all of Params in scratch for that pointer)
+    asm volatile("" : "+s"(q_sm.x), "+s"(q_sm.y), "+s"(q_sm.z), "+s"(q_sm.w), "+s"(t_sm.x), "+s"(t_sm.y), "+s"(t_sm.z));
+    if (P.pose_table) {       // a batch of poses: the lane's pose table, filled by k_set_poses ahead of the chain (rows of 8 floats)
+        const float4 a = P.pose_table[2 * frame], b = P.pose_table[2 * frame + 1];
+        q_sm = { a.x, a.y, a.z, a.w }; t_sm = { b.x, b.y, b.z };
     }
     if (P.motion_poses) {     // include_motion: Tsm looked up per azimuth (RadarCPU.cpp:190-196)
         const float* ps = P.motion_poses + 7 * ((size_t)(frame % P.motion_rows) * P.n_angles + az);
@@ -1439,15 +1439,15 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
 
 // first node of a replayed launch graph: the call's poses, passed by value, into the lane's pose table -- the ONE node whose
 // parameters change from replay to replay (hipGraphExecKernelNodeSetParams)
-__global__ void k_set_poses(const PoseArgs a, float* table)
+__global__ void k_set_poses(const PoseArgs a, float* table)      // table: rows of 8 floats (q.xyzw, t.xyz, 0)
 {
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i < 7 * a.n) table[i] = a.p[i / 7][i % 7];
+    if (i < 8 * a.n) table[i] = (i & 7) < 7 ? a.p[i >> 3][i & 7] : 0.0f;
 }
 void* set_poses_kernel() { return (void*)k_set_poses; }
 void launch_set_poses(const PoseArgs& a, float* table, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_set_poses, dim3(1), dim3(448), 0, s, a, table);
+    hipLaunchKernelGGL(k_set_poses, dim3(1), dim3(512), 0, s, a, table);
 }
 
 void launch_shade(const Params& P, int pass, hipStream_t s)
