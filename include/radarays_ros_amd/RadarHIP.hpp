@@ -153,6 +153,12 @@ public:
         msg->stamp = stamp; msg->frame_id = m_sensor_frame;   // RadarCPU.cpp:560-561
         return msg;
     }
+    // Offline generation (the twin of integration/src/radarays_ros/RadarHIP.cpp: simulateBatch / simulateSweeps): one image
+    // per pose [n][7], up to RR_MAX_BATCH poses per set of launches; with per-azimuth pose tables (include_motion,
+    // RadarCPU.cpp:190-196) sweeps = [n][n_angles][7], one table per frame (rr_multi_set_motion_poses)
+    std::vector<ImagePtr> simulateBatch(const std::vector<float>& poses, double stamp) { return batch(poses, false, stamp); }
+    std::vector<ImagePtr> simulateSweeps(const std::vector<float>& sweeps, double stamp) { return batch(sweeps, true, stamp); }
+
     // The gen_radar_image action of the optimisation loop (action/GenRadarImage.action,
     // scripts/radaray_opti.py:170-200), batched: one image per material table, same pose, one call.
     std::vector<ImagePtr> simulateMaterialSets(const std::vector<std::vector<RadarMaterial>>& sets, double stamp)
@@ -232,6 +238,35 @@ public:
     const rr_stats& lastStats() const { return m_stats; }
 
 private:
+    std::vector<ImagePtr> batch(const std::vector<float>& poses, bool sweeps, double stamp)
+    {
+        std::vector<ImagePtr> out;
+        if (!push()) return out;
+        const size_t per = sweeps ? 7 * (size_t)m_n_angles : 7;
+        if (poses.empty() || poses.size() % per) { m_err = "poses must be [n][7] (sweeps: [n][n_angles][7])"; return out; }
+        const size_t n_total = poses.size() / per, npx = (size_t)m_cfg.n_cells * m_n_angles;
+        std::vector<uint8_t> px((size_t)RR_MAX_BATCH * npx);
+        std::vector<float> first;
+        for (size_t at = 0; at < n_total; at += RR_MAX_BATCH) {
+            const size_t n = std::min(n_total - at, (size_t)RR_MAX_BATCH);
+            const float* p = poses.data() + at * per;
+            if (sweeps) {      // table k of the call = the per-azimuth poses of its frame k; the pose arguments are ignored but must be valid
+                first.clear();
+                for (size_t k = 0; k < n; k++) first.insert(first.end(), p + k * per, p + k * per + 7);
+                if (rr_multi_set_motion_poses(m_multi, p, n * (size_t)m_n_angles)) { mfail(); break; }
+            } else if (rr_multi_set_motion_poses(m_multi, nullptr, 0)) { mfail(); break; }
+            if (rr_multi_simulate_batch(m_multi, sweeps ? first.data() : p, (int)n, px.data())) { mfail(); break; }
+            for (size_t k = 0; k < n; k++) {
+                ImagePtr msg = std::make_shared<Image>();
+                msg->height = (uint32_t)m_cfg.n_cells; msg->width = (uint32_t)m_n_angles; msg->step = msg->width;
+                msg->data.assign(px.begin() + k * npx, px.begin() + (k + 1) * npx);
+                msg->stamp = stamp; msg->frame_id = m_sensor_frame;
+                out.push_back(msg);
+            }
+        }
+        m_push_motion = true;      // simulate() re-installs its own table (or none)
+        return out;
+    }
     // marshal the protected state of Radar into the context (what simulate() reads, Radar.hpp:66-105)
     bool push()
     {

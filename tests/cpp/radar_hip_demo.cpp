@@ -69,6 +69,23 @@ int main(int argc, char** argv)
             multi.updateDynCfg(cm); multi.setMotionPoses(sweep);
             ImagePtr img3 = multi.simulate(42.5);
             if (!img3 || img3->data != img->data) { std::fprintf(stderr, "include_motion sweep differs: %s\n", multi.lastError().c_str()); return 9; }
+            // offline generation: three poses in one set of launches; frame 0 is `pose`, frame 2 another one
+            std::vector<float> three;
+            for (int k = 0; k < 3; k++) { three.insert(three.end(), pose.begin(), pose.end()); three[7 * k + 4] += 0.25f * k; }
+            multi.updateDynCfg(cfg);
+            std::vector<ImagePtr> b3 = multi.simulateBatch(three, 50.0);
+            if (b3.size() != 3 || b3[0]->data != img->data || b3[2]->data == img->data || b3[1]->stamp != 50.0) {
+                std::fprintf(stderr, "simulateBatch: %s\n", multi.lastError().c_str()); return 19;
+            }
+            // ... and the same three frames as sweeps whose 400 poses are all equal: the same bytes, one table per frame
+            std::vector<float> sweeps3;
+            for (int k = 0; k < 3; k++) for (int a = 0; a < 400; a++) sweeps3.insert(sweeps3.end(), three.begin() + 7 * k, three.begin() + 7 * k + 7);
+            multi.updateDynCfg(cm);
+            std::vector<ImagePtr> s3 = multi.simulateSweeps(sweeps3, 51.0);
+            if (s3.size() != 3) { std::fprintf(stderr, "simulateSweeps: %s\n", multi.lastError().c_str()); return 20; }
+            for (int k = 0; k < 3; k++) if (s3[k]->data != b3[k]->data) { std::fprintf(stderr, "simulateSweeps: frame %d differs from simulateBatch\n", k); return 20; }
+            ImagePtr img4 = multi.simulate(42.5);                 // simulate() re-installs ITS sweep table
+            if (!img4 || img4->data != img->data) { std::fprintf(stderr, "simulate() after simulateSweeps differs\n"); return 21; }
         }
         // the optimiser's evaluation, batched (radaray_opti.py): three RadarParams -- the current ones, a narrower beam with
         // two passes, other materials with one pass -- as images and as scores against the first image
