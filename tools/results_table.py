@@ -6,7 +6,7 @@ tag = sys.argv[1]
 W = [("2. 400x200, 1 pass, 100k tris", "config2_100k_400x200_1pass"), ("3. 400x200, 4 passes, 1M tris", "config3_1M_400x200_4pass"),
      ("**north-star target**: 400x200, 4 passes, 10M tris", "target_10M_400x200_4pass"),
      ("4. 400x1000, 4 passes, 10M tris", "config4_10M_400x1000_4pass"), ("5. 400x1000, 8 passes, per-triangle materials, Cook-Torrance lobe", "config5_10M_400x1000_8pass_pertri")]
-print("| config | CPU img/s (threads of usable CPUs) | 1x MI355X img/s (`value`) | host-resident | 1 pose per launch set | one synchronous `rr_simulate` | wave-passes/s | dominant kernel: VALU issue frac alone / live / useful share | launch alone / live | strong-scaling bound of ONE frame at 2 / 4 / 8 GPUs |")
+print("| config | CPU img/s (threads of usable CPUs) | 1x MI355X img/s (`value`: through the last D2H copy) | images left in HBM (`hbm_resident`) | 1 pose per launch set | one synchronous `rr_simulate` | wave-passes/s | dominant kernel: VALU issue frac alone / live / useful share | launch alone / live | strong-scaling bound of ONE frame at 2 / 4 / 8 GPUs |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for label, w in W:
     f = os.path.join(R, "profiles", "%s_bench_%s.json" % (tag, w))
