@@ -131,6 +131,25 @@ def oru4_test_materials() -> List[RadarMaterial]:
             RadarMaterial(0.03, 1.0, 0.0, 100.0), RadarMaterial(0.0, 1.0, 0.0, 1.0)]
 
 
+def oru3_legacy_materials() -> List[RadarMaterial]:
+    """config/oru3.yaml (legacy structure-of-arrays table, read by src/ray_reflection_test.cpp:156-167): air + 11 geological
+    materials that all transmit (water 0.033 .. ice 0.16 m/ns) with fractional BRDF exponents (0.1 .. 0.8) + one opaque
+    material with exponent 0 (cos^0 = 1)."""
+    v = [0.3, 0.033, 0.01, 0.16, 0.15, 0.06, 0.12, 0.09, 0.07, 0.06, 0.13, 0.13, 0.0]
+    a = [0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 1.0, 0.5, 1.0]
+    d = [0.1, 0.1, 0.1, 0.3, 0.8, 0.8, 0.8, 0.8, 0.8, 0.8, 0.8, 0.8, 0.0]
+    s = [0.1, 0.8, 0.8, 0.6, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.0]
+    return [RadarMaterial(*t) for t in zip(v, a, d, s)]
+
+
+def oru4_legacy_materials() -> List[RadarMaterial]:
+    """config/oru4.yaml (legacy table): stone / wood with velocities of 0.001 / 0.002 m/ns (n21 = 300: no total reflection
+    limit, a refraction direction almost along the normal), glass 0.05 with ambient 0.01 and exponent 2000, metal, and a
+    "test" material with exponent 0."""
+    return [RadarMaterial(0.3, 0.5, 0.1, 0.1), RadarMaterial(0.001, 0.6, 0.3, 30.0), RadarMaterial(0.002, 0.6, 0.3, 70.0),
+            RadarMaterial(0.05, 0.01, 0.04, 2000.0), RadarMaterial(0.0, 1.0, 1.0, 2000.0), RadarMaterial(0.0, 1.0, 0.0, 0.0)]
+
+
 # config/oru4_test.yaml:37-56 (the same list closes config/mulran_kaist02.yaml:24-43): material of each of the 18 objects
 # of the ORU4 scene, in the order rmagine numbers the geometries of the .dae (ground, door glass, wall, door wood, ...)
 ORU4_OBJECT_MATERIALS = [1, 3, 1, 2, 3, 3, 2, 2, 3, 3, 2, 2, 4, 2, 4, 2, 4, 1]

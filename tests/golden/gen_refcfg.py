@@ -8,6 +8,9 @@ Sources (nothing but values leaves them):
   cfg/mulran_kaist_dyncfg{,_laserlike,_minimal}.yaml   the three dynamic-reconfigure presets (`dynparam load` files): the
                                                   top-level `dictitems` (the nested `groups` copy is dropped)
   config/mulran_kaist02.yaml, config/oru4_test.yaml    material tables: `materials`, `material_id_air`, `object_materials`
+  config/oru3.yaml, config/oru4.yaml              the LEGACY structure-of-arrays tables (`velocities`, `ambient`, `diffuse`, `specular`;
+                                                  read by src/ray_reflection_test.cpp:156-167 only): 13 geological / 6 office materials
+                                                  with velocities down to 0.001 and fractional or zero BRDF exponents
 A preset file sets only the keys it holds; what `dynparam load` leaves alone keeps the .cfg default.  Keys of a preset
 that the .cfg no longer declares (particle_noise*, from an older version of the package) are listed under "stale_keys".
 """
@@ -59,6 +62,14 @@ def main():
         doc["materials"][name] = {
             "materials": [[m["velocity"], m["ambient"], m["diffuse"], m["specular"]] for m in d["materials"]],
             "material_id_air": d["material_id_air"], "object_materials": d["object_materials"]}
+    doc["materials_legacy"] = {}
+    for name in ("oru3", "oru4"):
+        d = yaml.safe_load(open(os.path.join(REF, "config", name + ".yaml")))
+        n = len(d["velocities"])
+        assert all(len(d[k]) == n for k in ("ambient", "diffuse", "specular"))
+        doc["materials_legacy"][name] = {
+            "materials": [[d["velocities"][i], d["ambient"][i], d["diffuse"][i], d["specular"][i]] for i in range(n)],
+            "material_id_air": d.get("material_id_air", 0), "object_materials": d.get("object_materials")}
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
     print("wrote", OUT)

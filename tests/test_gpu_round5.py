@@ -269,6 +269,23 @@ def test_oru4_test_materials_on_an_18_object_scene_through_the_c_loader(native_l
     assert st["wave_passes"] > ost["wave_passes"] and not np.array_equal(o8, g8)
 
 
+@pytest.mark.parametrize("table", ["oru4_legacy", "oru3_legacy"])
+def test_legacy_material_tables_on_the_18_object_scene(native_lib, oracle, table):
+    """The reference's legacy material tables (config/oru4.yaml, config/oru3.yaml; values pinned by tests/test_ref_presets.py)
+    on the 18-object scene, 5 passes: velocities of 0.001 / 0.002 m/ns (n21 = 300), eleven transmitting geological materials,
+    BRDF exponents of 0 (cos^0 = 1), 0.1 and 2000, ambient 0.01 -- wave, hit and signal counts exact, deviation <= 1e-5."""
+    s = scenes.oru4_like_scene()
+    if table == "oru4_legacy":
+        mats, objmat = params.oru4_legacy_materials(), params.ORU4_OBJECT_MATERIALS
+    else:
+        mats = params.oru3_legacy_materials()
+        objmat = [1 + (k * 5) % 12 for k in range(18)]          # every one of the 12 non-air materials is on some object
+        assert set(objmat) == set(range(1, 13))
+    cfg = params.kaist_preset(ambient_noise=0, n_samples=40, n_reflections=5)
+    g8, st = _render_and_compare(native_lib, oracle, s, cfg, mats, objmat, golden_beams(40), scenes.default_pose(s["name"]), use_bvh=0)
+    assert st["wave_passes"] > 400 * 40 * 2 and (g8 > 0).mean() > 0.01
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Tight later-pass trace rows (rr_get_trace_grid): images never depend on the history
 # ---------------------------------------------------------------------------------------------------------------------

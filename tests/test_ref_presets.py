@@ -58,3 +58,13 @@ def test_material_tables_equal_the_reference_yaml():
     # mulran_kaist02 lists materials 2..4 for objects its two-entry table does not have: with a one-object MulRan map
     # only object 0 (-> material 1) is ever looked up; any further object would index past the table in the reference
     assert max(k["object_materials"]) >= len(k["materials"]) and k["object_materials"][0] == 1
+
+
+def test_legacy_material_tables_equal_the_reference_yaml():
+    """config/oru3.yaml / oru4.yaml: the structure-of-arrays tables src/ray_reflection_test.cpp:156-167 reads -- 13 and 6 materials
+    whose corner values (velocities of 0.001, BRDF exponents of 0 and 0.1) are parity cases of tests/test_gpu_round5.py."""
+    for name, fn in (("oru3", params.oru3_legacy_materials), ("oru4", params.oru4_legacy_materials)):
+        want = REF["materials_legacy"][name]["materials"]
+        assert [list(m.astuple()) for m in fn()] == want and REF["materials_legacy"][name]["material_id_air"] == 0
+    assert len(params.oru3_legacy_materials()) == 13 and len(params.oru4_legacy_materials()) == 6
+    assert REF["materials_legacy"]["oru4"]["object_materials"] == params.ORU4_OBJECT_MATERIALS
