@@ -319,6 +319,7 @@ def test_tight_trace_rows_follow_the_history_and_never_change_an_image(native_li
         c.set_beam_samples(golden_beams(64))
         return c
     monkeypatch.delenv("RR_TIGHT_FORCE", raising=False)                    # (the suite may run under it)
+    monkeypatch.delenv("RR_STACK_LDS", raising=False)                      # (... or under the spill path, whose launches keep full rows)
     monkeypatch.setenv("RR_TIGHT_GRID", "0")
     c0 = ctx()
     want_calm, want_busy = _batch(c0, calm, cfg), _batch(c0, busy, cfg)
