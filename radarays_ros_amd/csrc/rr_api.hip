@@ -146,6 +146,7 @@ struct rr_ctx {
     std::vector<float> noise;
     int noise_rows = 1;
     int motion_rows = 1;
+    bool motion_live = false;    // a motion table was in use at the last upload (Params::motion_poses non-null)
     std::vector<float> motion;   // [n_angles][7] or empty
     std::vector<float> smear;
     int smear_mode = 0;
@@ -324,7 +325,12 @@ int upload_tables(rr_ctx* c)
     const rr_config& g = c->cfg;
     const unsigned dirty = c->tables_dirty;
     if (dirty & (rr_ctx::D_CFG | rr_ctx::D_BEAMS | rr_ctx::D_MAT)) c->hist_gen++;     // wave counts per pass change: the trace-grid history starts over
-    c->graph_gen++;            // captured launches hold table pointers and scalars of the old parameters
+    // captured launches (launch graphs) hold table pointers and scalars of the old parameters.  Fresh noise offsets or motion
+    // tables of the SAME shape -- what a node sets before every frame (RadarCPU.cpp:461-472, :190-196) -- only change the
+    // contents of a buffer the graphs already point at
+    bool regen = (dirty & (rr_ctx::D_CFG | rr_ctx::D_BEAMS | rr_ctx::D_MAT)) != 0;
+    const void* noise_before = c->d_noise.p; const int noise_rows_before = c->noise_rows;
+    const void* motion_before = c->motion_live ? (const void*)c->d_motion.p : nullptr; const int motion_rows_before = c->motion_rows;
     if (dirty & rr_ctx::D_CFG) {
     // Tas.R = EulerAngles{0,0,theta(angle)} -> quaternion (rmagine ZYX), RadarCPU.cpp:202
     std::vector<float4> qas((size_t)g.n_angles);
@@ -409,6 +415,10 @@ int upload_tables(rr_ctx* c)
         RR_HIP(c, c->d_motion.ensure(c->motion.size()));
         RR_HIP(c, hipMemcpy(c->d_motion.p, c->motion.data(), c->motion.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    c->motion_live = !c->motion.empty();
+    const void* motion_after = c->motion_live ? (const void*)c->d_motion.p : nullptr;
+    if (regen || noise_before != (const void*)c->d_noise.p || noise_rows_before != c->noise_rows ||
+        motion_before != motion_after || motion_rows_before != c->motion_rows) c->graph_gen++;
     c->tables_dirty = 0;
     return 0;
 }

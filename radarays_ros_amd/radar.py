@@ -51,6 +51,7 @@ class RadarHIP:
         self.Tsm_last = None
         self._beam_seed = beam_seed
         self._noise_seed = 7
+        self._motion = None
         self._ctx = native.Context(device)
         self._ctx.set_mesh(verts, faces, face_object_id)
         self._dirty_cfg = True
@@ -139,6 +140,42 @@ class RadarHIP:
         self.last_f32 = f32
         self.last_stats = stats
         return msg
+
+    def _batch(self, poses, sweeps, stamp):
+        """Offline generation (the twin of integration/.../RadarHIP.cpp: simulateBatch / simulateSweeps): one image per pose,
+        up to 64 poses per set of launches, delivered to page-locked host memory (rr_simulate_batch_host_async)."""
+        self._push()
+        out = []
+        poses = np.ascontiguousarray(poses, np.float32)
+        n_total = len(poses)
+        for at in range(0, n_total, 64):
+            chunk = poses[at:at + 64]
+            if sweeps:         # chunk: [n][n_angles][7] -- table k = the per-azimuth poses of frame k (RadarCPU.cpp:190-196)
+                self._ctx.set_motion_poses(chunk.reshape(-1, 7))
+                first = np.ascontiguousarray(chunk[:, 0, :])
+            else:
+                self._ctx.set_motion_poses(None)
+                first = chunk
+            h = native.HostImages((len(chunk), self.m_cfg.n_cells, N_ANGLES))
+            try:
+                self._ctx.simulate_batch_host_async(first, h.ptr)
+                self._ctx.wait_host(h.ptr)
+                for k in range(len(chunk)):
+                    u8 = h.array[k].copy()
+                    out.append(Image(header=Header(stamp=stamp, frame_id=self.m_sensor_frame), height=u8.shape[0], width=u8.shape[1],
+                                     encoding="mono8", step=u8.shape[1], data=u8))
+            finally:
+                h.close()
+        self._ctx.set_motion_poses(self._motion if getattr(self, "_motion", None) is not None else None)
+        return out
+
+    def simulateBatch(self, poses, stamp=0.0):
+        """[n][7] poses -> n Images (one set of launches per 64 poses)."""
+        return self._batch(np.asarray(poses, np.float32).reshape(-1, 7), False, stamp)
+
+    def simulateSweeps(self, sweeps, stamp=0.0):
+        """include_motion: [n][400][7] per-azimuth pose tables -> n Images, one table per frame of a batch."""
+        return self._batch(np.asarray(sweeps, np.float32).reshape(-1, N_ANGLES, 7), True, stamp)
 
     def simulateMaterialSets(self, sets, stamp=0.0):
         """The gen_radar_image action of the optimisation loop (action/GenRadarImage.action,

@@ -108,6 +108,28 @@ def test_include_motion_through_the_batch_path(native_lib, motion_case):
     c.close()
 
 
+def test_python_mirror_batches_and_sweeps(native_lib, motion_case):
+    """radar.py: RadarHIP.simulateBatch / simulateSweeps (the twins of the ROS-typed adapter's methods): byte-equal to the same
+    frames through simulate(), one by one."""
+    from radarays_ros_amd.radar import RadarHIP
+    s, cfg, mats, beams, sweeps, want = motion_case
+    r = RadarHIP(s["verts"], s["faces"], s["face_object_id"])
+    r.loadParams(mats, s["object_materials"], 0)
+    r.updateDynCfg(cfg)
+    r.setBeamSamples(beams)
+    imgs = r.simulateSweeps(sweeps[:3], stamp=7.0)
+    assert len(imgs) == 3 and imgs[1].header.stamp == 7.0 and imgs[0].encoding == "mono8"
+    for f in range(3):
+        d = np.abs(imgs[f].data.astype(int) - want[f][0].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, f
+    static = r.simulateBatch(sweeps[:3, 0], stamp=8.0)
+    r.updateDynCfg(cfg.copy(include_motion=False))
+    for f in range(3):
+        r.updateTsm(sweeps[f, 0])
+        assert np.array_equal(static[f].data, r.simulate().data), f
+    assert not np.array_equal(static[0].data, imgs[0].data)
+
+
 @pytest.mark.parametrize("n_dev", [1, 3, 8])
 def test_include_motion_through_rr_multi(native_lib, motion_case, monkeypatch, n_dev):
     """The same 8 sweeps through rr_multi_set_motion_poses + rr_multi_simulate_batch: one device (host-delivery route) and
@@ -419,11 +441,26 @@ def test_launch_graphs_replay_identical_images_and_are_dropped_on_any_change(nat
     for _ in range(3):
         assert np.array_equal(run(batches[0]), want_other)
     assert not np.array_equal(want_other, want[0]) and c.graph_stats()[0] > cap2
+    # fresh noise offsets of the same shape (what a node sets before every frame, RadarCPU.cpp:461-472) keep the graphs: only
+    # the contents of a buffer they already point at change -- and the images follow the new offsets
+    noise2 = (np.random.RandomState(4).uniform(0, 1, (4, 400)) * 1000.0).astype(np.float32)
+    c.set_noise_offsets(noise2); c0.set_noise_offsets(noise2)
+    want_n2 = _batch(c0, batches[0], cfg)
+    before = c.graph_stats()
+    for _ in range(2):
+        assert np.array_equal(run(batches[0]), want_n2)
+    after = c.graph_stats()
+    assert after[0] == before[0] and after[1] == before[1] + 2 and not np.array_equal(want_n2, want_other)
+    c.set_noise_offsets(noise2[:1]); c0.set_noise_offsets(noise2[:1])          # another shape: one row -> captured again
+    want_n1 = _batch(c0, batches[0], cfg)
+    for _ in range(3):
+        assert np.array_equal(run(batches[0]), want_n1)
+    assert c.graph_stats()[0] == after[0] + 1
     # instrumented runs are issued kernel by kernel
     c.set_timing_mode(1)
     before = c.graph_stats()
     for _ in range(3):
-        assert np.array_equal(run(batches[0]), want_other)
+        assert np.array_equal(run(batches[0]), want_n1)
     assert c.graph_stats() == before
     c.set_timing_mode(0)
     # an overflow inside a replayed chain is still reported
