@@ -400,7 +400,7 @@ def main():
         wave_passes_batch = wave_passes_batch_rank
 
     # ---- N = 1 extras: the image delivered to host memory; one pose per launch set ---------------------------
-    hbm_res = single = sync1 = proxy = None
+    hbm_res = single = sync1 = proxy = wproxy = None
     if world == 1 and not args.no_extras and not args.force_slots:
         npx = cfg.n_cells * params.N_ANGLES
         for h in hosts:
@@ -467,6 +467,51 @@ def main():
         proxy["what"] = ("one frame's kernel chain for a block of 400/N columns alone on the GPU vs all 400: an upper bound of the "
                          "strong-scaling speed-up of ONE frame on N GPUs (efficiency = strong_ceiling_N); the default N > 1 mode of "
                          "this bench is WEAK scaling (N x frames per batch), which keeps every GPU's launches as large as at N = 1")
+        # weak-scaling proxy on ONE GPU: the work of rank 0 of N -- its 400/N-column block of N x F frames in one set of
+        # launches, then the transpose of the F frames it ends up with -- against the N = 1 step (all 400 columns of F
+        # frames).  Same number of segments per launch by construction; what can differ is the cost of many frames'
+        # narrow blocks (pass-0 tiles, per-frame tables, the transpose from [frame][50][cells] pieces).  The collective
+        # itself (F x 1.37 MB in and out per rank per batch) is NOT in it
+        wproxy = None
+        Fw = args.frames_per_rank
+        if Fw * 8 <= 64:
+            wstreams = [torch.cuda.Stream(device=dev) for _ in range(args.slots)]
+            wproxy = {}
+            base_ms = None
+            for n_sh in (1, 2, 4, 8):
+                b, e = native.partition(params.N_ANGLES, n_sh, 0)
+                nl = e - b
+                nfr = n_sh * Fw
+                blocks = [torch.zeros((nfr, nl, cfg.n_cells), dtype=torch.uint8, device=dev) for _ in range(args.slots)]
+                imgs_w = [torch.zeros((Fw, cfg.n_cells, params.N_ANGLES), dtype=torch.uint8, device=dev) for _ in range(args.slots)]
+                state_w = {"n": 0}
+
+                def step_w(k):
+                    for bb in range(bps):
+                        n = state_w["n"]; state_w["n"] += 1
+                        st_ = wstreams[n % args.slots]
+                        pl = [poses[((k * bps + bb) * nfr + f) % len(poses)] for f in range(nfr)]
+                        ctx.simulate_batch_columns_device(pl, b, e, blocks[n % args.slots].data_ptr(), st_.cuda_stream)
+                        # the rank's own F frames, as the all_to_all would deliver them: [source rank][F][nl][cells]
+                        ctx.assemble_frames_device(blocks[n % args.slots].data_ptr(), nl, Fw * nl * cfg.n_cells, Fw, nl * cfg.n_cells,
+                                                   imgs_w[n % args.slots].data_ptr(), st_.cuda_stream)
+                prewarm(step_w)
+                torch.cuda.synchronize()
+                tw0 = time.perf_counter()
+                n_st = max(args.steps // 2, 10)
+                for k in range(n_st):
+                    step_w(k)
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - tw0) / n_st
+                if n_sh == 1:
+                    base_ms = ms
+                wproxy["ms_per_step_rank0_of_%d" % n_sh] = round(ms, 4)
+                wproxy["weak_ceiling_%d" % n_sh] = round(base_ms / ms, 4)
+                del blocks, imgs_w
+            wproxy["what"] = ("per-GPU step time of the weak-scaling shape on ONE GPU: rank 0 of N renders its 400/N-column block of N x %d "
+                              "frames per batch and transposes the %d frames it would own, against N = 1 (400 columns of %d frames); "
+                              "weak_ceiling_N = what N GPUs could reach of N x the single-GPU rate before the collective (%.1f MB in and "
+                              "out per rank per batch over xGMI) is paid; images left in HBM" % (Fw, Fw, Fw, Fw * cfg.n_cells * params.N_ANGLES / 1e6))
 
     # ---- N > 1: what a reader needs to believe RCCL saw N ranks ------------------------------------------------
     rccl = None
@@ -613,6 +658,7 @@ def main():
             "single_pose": single,
             "single_frame_sync": sync1,
             "strong_scaling_proxy": proxy,
+            "weak_scaling_proxy": wproxy,
             "roofline": roof,
         }
 
