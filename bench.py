@@ -38,7 +38,8 @@ N > 1 also carries `rccl` -- what a reader needs to believe RCCL saw N ranks: wo
 reports them, every rank's device (index, name, PCI bus id), the collective and its bytes, every rank's own images/s and the
 slowest rank -- and `n1_reference`, the N = 1 figure of the same workload from profiles/.
 
-Also on the line: `single_frame_sync` (ONE synchronous rr_simulate per frame: the reference's own call shape,
+Also on the line: `weak_scaling_proxy` (the per-step work of rank 0 of N -- its 400/N-column block of N x F frames and the
+transpose of its F frames -- on this one GPU against the N = 1 step: the per-GPU side of weak scaling), `single_frame_sync` (ONE synchronous rr_simulate per frame: the reference's own call shape,
 radar_simulator.cpp:197-212) and `strong_scaling_proxy` (a block of 400/N azimuth columns alone on the GPU against the
 whole frame: the bound of what sharding ONE frame over N GPUs can win; the default N > 1 mode is weak scaling).
 
