@@ -15,7 +15,7 @@
 #include <vector>
 
 namespace rr {
-void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_shade(const Params& P, int pass, hipStream_t s);
 void launch_scan(const Params& P, int pass, hipStream_t s);
 void launch_column(const Params& P, hipStream_t s);
@@ -31,8 +31,8 @@ void launch_debug_trace(const Params& P, const float* origs, const float* dirs, 
                         float* out_t, uint32_t* out_face, hipStream_t s, unsigned long long* steps = nullptr);
 void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s, size_t n_tris);
 void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s);
-void launch_set_poses(const PoseArgs& a, float* table, hipStream_t s);
-void* set_poses_kernel();
+void* trace0_kernel(bool spill);
+Params trace0_params(const Params& P);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
 }  // namespace rr
 
@@ -93,16 +93,18 @@ struct Lane {
     // and the page-locked copy of the history that arrives behind every batch (read without a fence: it is a hint)
     DevBuf<GridHint> d_hint; DevBuf<uint32_t> d_ovf_list; int ovf_stride = 0;
     uint32_t* h_hist = nullptr; int hist_gen = 0;
-    // Launch graphs (round 5): the launch chain of a batch -- pose upload, n_reflections x {trace [+ repair], shade, scan},
-    // column, history copy -- captured once per (azimuth block, frames, output buffer, trace rows) and replayed with ONE
-    // hipGraphLaunch; the poses are the only thing that changes between replays (k_set_poses' parameters).  Host time per
+    // Launch graphs (round 5): the launch chain of a batch -- n_reflections x {trace [+ repair], shade, scan}, column, history
+    // copy -- captured once per (azimuth block, frames, output buffer, trace rows) and replayed with ONE hipGraphLaunch; the
+    // poses are the only thing that changes between replays (the third argument of the pass-0 trace node).  Host time per
     // chain: 46 us launched kernel by kernel (16 launches) against ~11 us replayed (tools/cpp_bench.cpp graph)
     struct FrameGraph {
         int az_begin = 0, az_end = 0, n_frames = 0; const void* cols = nullptr; unsigned short rows[kMaxPasses] = {};
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; hipGraphNode_t pose_node = nullptr; uint64_t last_use = 0; int hits = 0;
+        hipKernelNodeParams pose_kp{};     // the pass-0 trace node as captured (grid, block, LDS) ...
+        Params pose_P;                     // ... and the Params bytes it was captured with
     };
     std::vector<FrameGraph> graphs; int graph_gen = 0;
-    DevBuf<float> d_poses;       // [RR_MAX_BATCH][8]: Params::pose_table of the replayed launches
+    DevBuf<float> d_poses;       // [RR_MAX_BATCH][8]: Params::pose_table, written by the pass-0 trace launch of every chain
     unsigned short last_rows[kMaxPasses] = {};     // rows the lane's last batch was launched with (0: the bound)
 
     hipStream_t stream = nullptr;
@@ -526,8 +528,6 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.cflag = L.d_cflag.p; P.sigtmp = L.d_sigtmp.p; P.hit = L.d_hit.p;
     P.sig = L.d_sig.p; P.sig_count = L.d_sig_count.p; P.spill = L.d_spill.p; P.counters = L.d_counters.p; P.sticky = L.d_sticky.p; P.seg_stats = L.d_seg_stats.p;
     P.cols_u8 = d_cols_u8; P.cols_f32 = d_cols_f32;
-    P.q_sm = { pose[0], pose[1], pose[2], pose[3] };
-    P.t_sm = { pose[4], pose[5], pose[6] };
     P.az_begin = az_begin; P.n_seg = n_seg;
     P.n_beam = (int)(c->beams.size() / 3); P.cap = L.buf_cap; P.sigcap = L.buf_sigcap;
     P.n_cells = g.n_cells; P.n_angles = g.n_angles;
@@ -675,6 +675,13 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         }
     }
     std::memcpy(L.last_rows, P.tight_groups, sizeof(L.last_rows));
+    // the poses of the call ride in the pass-0 trace launch (by value), which also writes them into the lane's pose table for
+    // the launches behind it; a parameter batch (every set the same pose) and a single frame use row 0
+    PoseArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.n = d_matsets ? 1 : n_frames;
+    for (int f = 0; f < pa.n; f++) for (int k = 0; k < 7; k++) pa.p[f][k] = pose[7 * f + k];
+    P.pose_table = reinterpret_cast<float4*>(L.d_poses.p);
     // the launch chain of the batch
     auto enqueue = [&](Params& Q) -> int {
     for (int pass = 0; pass < g.n_reflections; pass++) {
@@ -690,10 +697,10 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         if (c->timing) {
             // the kernel's own begin/end timestamps (hipExtLaunchKernel events), on its launch stream
             hipEvent_t a = c->take_event(), b = c->take_event();
-            launch_trace(Q, pass, c->stats_mode, s, a, b);
+            launch_trace(Q, pass, &pa, c->stats_mode, s, a, b);
             c->timers[pass == 0 ? "trace0" : "trace"].pending.emplace_back(a, b);
         } else {
-            launch_trace(Q, pass, c->stats_mode, s);
+            launch_trace(Q, pass, &pa, c->stats_mode, s);
         }
         if (c->roctx) roctx_pop();
         { TimedScope t(c, s, "shade"); launch_shade(Q, pass, s); }
@@ -709,20 +716,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     // batches: no carried host copy (its pointers move from call to call), no parameter batch, no timing / statistics /
     // roctx instrumentation; whatever a captured launch bakes in is covered by graph_gen (tables, tree, lane buffers) or
     // by the key (azimuth block, frames, output buffer, trace rows)
-    // a batch of poses travels through the lane's pose table (k_set_poses ahead of the chain); one frame / a parameter batch
-    // (every set the same pose) use q_sm / t_sm
-    const bool pose_batch = n_frames > 1 && !d_matsets;
-    PoseArgs pa;
-    float* table = L.d_poses.p;
-    if (!d_matsets) {
-        std::memset(&pa, 0, sizeof(pa));
-        pa.n = n_frames;
-        for (int f = 0; f < n_frames; f++) for (int k = 0; k < 7; k++) pa.p[f][k] = pose[7 * f + k];
-    }
-    if (pose_batch) P.pose_table = reinterpret_cast<const float4*>(table);
     if (L.graph_gen != c->graph_gen) { drop_graphs(L); L.graph_gen = c->graph_gen; }
-    // (a single frame issued kernel by kernel keeps its pose by value -- no extra launch on the latency path; its REPLAYED chain
-    // reads the table like any other)
     const bool graphable = !d_matsets && c->use_graphs && !copy_src && !c->timing && !c->stats_mode && !c->roctx && !d_cols_f32 && g.n_reflections > 0;
     if (graphable) {
         Lane::FrameGraph* fg = nullptr;
@@ -745,10 +739,9 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         }
         fg->last_use = ++c->graph_clock;
         if (!fg->ge && fg->hits >= 1) {            // the second call with this shape: worth a capture
-            Params Q = P; Q.pose_table = reinterpret_cast<const float4*>(table);
+            Params Q = P;
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
-                launch_set_poses(pa, table, s);
                 const int rcq = enqueue(Q);
                 hipGraph_t gph = nullptr;
                 e = hipStreamEndCapture(s, &gph);
@@ -760,7 +753,9 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
                         for (hipGraphNode_t nd : nodes) {
                             hipGraphNodeType ty; hipKernelNodeParams kp{};
                             if (hipGraphNodeGetType(nd, &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
-                                hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == set_poses_kernel()) { fg->pose_node = nd; break; }
+                                hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == trace0_kernel(P.spill_depth > 0)) {
+                                fg->pose_node = nd; fg->pose_kp = kp; fg->pose_P = trace0_params(P); break;
+                            }
                         }
                         if (fg->pose_node) { fg->g = gph; fg->ge = ge; c->graph_captures++; }
                         else { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gph); }
@@ -771,9 +766,10 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
             if (!fg->ge) fg->hits = -1000000;      // capture is not available here: stay with plain launches for this shape
         }
         if (fg->ge) {
-            void* args[2] = { (void*)&pa, (void*)&table };
-            hipKernelNodeParams kp{};
-            kp.func = set_poses_kernel(); kp.gridDim = dim3(1); kp.blockDim = dim3(512); kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
+            int pass0 = 0;
+            void* args[3] = { (void*)&fg->pose_P, (void*)&pass0, (void*)&pa };
+            hipKernelNodeParams kp = fg->pose_kp;
+            kp.kernelParams = args; kp.extra = nullptr;
             hipError_t e = hipGraphExecKernelNodeSetParams(fg->ge, fg->pose_node, &kp);
             if (e == hipSuccess) e = hipGraphLaunch(fg->ge, s);
             if (e != hipSuccess) return fail(c, -100, std::string("launch graph replay: ") + hipGetErrorString(e));
@@ -782,7 +778,6 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         }
         fg->hits++;
     }
-    if (pose_batch) launch_set_poses(pa, table, s);
     { const int rcq = enqueue(P); if (rcq) return rcq; }
     RR_HIP(c, hipGetLastError());
     return 0;

@@ -145,16 +145,16 @@ struct Params {
     uint8_t* cols_u8;            // [n_seg][n_cells]
     float* cols_f32;             // optional
     // scalars
-    Quat q_sm; V3 t_sm;
     int az_begin, n_seg;
     // frame batch: segment s belongs to frame s / n_loc and azimuth az_begin + s % n_loc
     int n_loc, n_frames;
-    // the poses of a batch: [n_frames][2] float4 = (q.xyzw)(t.xyz, 0) in the lane's device table, written by k_set_poses -- the
-    // first launch of the chain, whose by-value argument carries them (and the ONE node whose parameters change when the
-    // chain is replayed from a launch graph).  Null: every frame uses q_sm / t_sm (a single frame; a parameter batch).
-    // (Until round 5 the poses of frames 1..63 rode in Params itself: 1.8 KB of every kernel's arguments; a build that
-    // read them from EITHER place made the compiler copy all of Params into scratch -- 2.6 KB per lane, 7 waves per SIMD)
-    const float4* pose_table;
+    // the poses of the call: [n_frames][2] float4 = (q.xyzw)(t.xyz, 0) in the lane's device table (one row for a single frame
+    // and for a parameter batch, whose sets share one pose).  The pass-0 k_trace launch -- the first of every chain --
+    // carries them by value (PoseArgs below), uses them for its own rays and has its first workgroup write the table that
+    // every later launch of the chain reads.  It is also the ONE node whose parameters change when the chain is replayed
+    // from a launch graph.  No kernel reads a pose from two places: a build that chose between a by-value pose and the
+    // table made the compiler copy all of Params into scratch (2.6 KB per lane, 7 waves per SIMD; tests/test_kernel_resources.py)
+    float4* pose_table;
     int n_beam, cap, sigcap;
     int n_cells, n_angles, n_materials, n_objects, material_id_air;
     int n_passes, record_multi_reflection, record_multi_path;
@@ -180,7 +180,10 @@ struct Params {
     unsigned short tight_groups[kMaxPasses];   // 16-ray workgroups per segment row of pass p; 0: the full doubling bound
 };
 
-struct PoseArgs { float p[64][7]; int n; };     // RR_MAX_BATCH poses by value (k_set_poses)
+struct PoseArgs { float p[64][7]; int n; };     // RR_MAX_BATCH poses by value: third argument of the pass-0 k_trace
+struct NoPoses {};                              // ... and of the later passes
+template <bool FIRST> struct PosesOf { using type = NoPoses; };
+template <> struct PosesOf<true> { using type = PoseArgs; };
 
 __host__ __device__ inline int passes_of(const Params& P, int frame) { return P.set_mode ? (int)P.frame_passes[frame] : P.n_passes; }
 __host__ __device__ inline int beam_base(const Params& P, int frame) { return P.set_mode ? (int)P.frame_beam[frame] * P.n_beam : 0; }

@@ -25,16 +25,20 @@ namespace rr {
 __device__ inline Quat ld_quat(const float4* p) { const float4 v = *p; return { v.x, v.y, v.z, v.w }; }
 
 // Tam = Tsm * Tas (RadarCPU.cpp:201-206); Tas.t = 0.
-__device__ inline void azimuth_frame(const Params& P, int seg, Quat& q_am, V3& t_am)
+// ARGS: the pass-0 trace launch reads the call's poses from its own by-value argument; everything behind it from the lane's
+// pose table, which that launch wrote (rr_device.h: Params::pose_table)
+template <bool ARGS>
+__device__ __forceinline__ void azimuth_frame(const Params& P, const PoseArgs* pa, int seg, Quat& q_am, V3& t_am)
 {
     const int frame = seg / P.n_loc, az = P.az_begin + seg % P.n_loc;
     const Quat q_as = ld_quat(P.q_as + az);
-    Quat q_sm = P.q_sm; V3 t_sm = P.t_sm;
-    // (the by-value pose is pinned in registers HERE: left as loads, the compiler sinks them below the branch as ONE load through
-    // a pointer that is either &P.q_sm or the table -- and keeps a private copy of all of Params in scratch for that pointer)
-    asm volatile("" : "+s"(q_sm.x), "+s"(q_sm.y), "+s"(q_sm.z), "+s"(q_sm.w), "+s"(t_sm.x), "+s"(t_sm.y), "+s"(t_sm.z));
-    if (P.pose_table) {       // a batch of poses: the lane's pose table, filled by k_set_poses ahead of the chain (rows of 8 floats)
-        const float4 a = P.pose_table[2 * frame], b = P.pose_table[2 * frame + 1];
+    const int row = P.set_mode ? 0 : frame;      // a parameter batch: every set the same pose
+    Quat q_sm; V3 t_sm;
+    if constexpr (ARGS) {
+        const float* ps = pa->p[row];
+        q_sm = { ps[0], ps[1], ps[2], ps[3] }; t_sm = { ps[4], ps[5], ps[6] };
+    } else {
+        const float4 a = P.pose_table[2 * row], b = P.pose_table[2 * row + 1];
         q_sm = { a.x, a.y, a.z, a.w }; t_sm = { b.x, b.y, b.z };
     }
     if (P.motion_poses) {     // include_motion: Tsm looked up per azimuth (RadarCPU.cpp:190-196)
@@ -261,7 +265,7 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
 // one 16-ray group (= one wave) of a trace launch: group gx of segment row seg_y (pass 0: tile gx of the flat sequence)
 template <bool FIRST, bool STATS, bool SPILL, bool CULL>
 __device__ __forceinline__ void trace_group(const Params& P, const int pass, const int seg_y, const int gx, const int count,
-                                            uint32_t* lds_stack, const int gdim_x)
+                                            uint32_t* lds_stack, const int gdim_x, const PoseArgs* poses = nullptr)
 {
     const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int cur = pass & 1;
@@ -304,7 +308,7 @@ __device__ __forceinline__ void trace_group(const Params& P, const int pass, con
             }
         }
         Quat q_am; V3 t_am;
-        azimuth_frame(P, seg, q_am, t_am);
+        azimuth_frame<FIRST>(P, poses, seg, q_am, t_am);
         // (pass 0: every ray starts in the sensor's origin -- rotating the zero vector is +-0, see azimuth_frame)
         R = ray_setup(FIRST ? t_am : v_add(q_rot(q_am, orig), t_am), q_rot(q_am, dir));
     }
@@ -348,7 +352,7 @@ __device__ __forceinline__ void trace_group(const Params& P, const int pass, con
 
 // grid: (ceil(bound/16) [+ a copy row], n_seg), block 64 (= one wave = 16 rays), dynamic LDS = stack_lds * 16 * (4 | 6) B
 template <bool FIRST, bool STATS, bool SPILL, bool CULL>
-__global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass)
+__global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass, const typename PosesOf<FIRST>::type poses)
 {
     // k_trace is the long pole of a step: its waves go first when they share a SIMD with the
     // column / shade waves of the other steps in flight (config 2: live launch 135 -> 122 us)
@@ -358,6 +362,10 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     if (FIRST && blockIdx.x == 0 && blockIdx.y == 0) {
         if (threadIdx.x == 0) P.counters->overflow = 0;   // error bits of this frame
         if (P.grid_hint && threadIdx.x < kMaxPasses) P.grid_hint->ovf_n[threadIdx.x] = 0;   // overflow lists of the tightened rows
+        if constexpr (FIRST) {      // the poses, for every launch behind this one (rows of 8 floats: q.xyzw, t.xyz, 0)
+            float* table = reinterpret_cast<float*>(P.pose_table);
+            for (int i = threadIdx.x; i < 8 * poses.n; i += kTraceThreads) table[i] = (i & 7) < 7 ? poses.p[i >> 3][i & 7] : 0.0f;
+        }
     }
     // pass 0: the rays of ALL segments of the launch are tiled into waves of (16 / A) beam samples x A
     // neighbouring azimuths (A = pass0_az = 16: ONE sample in 16 azimuths, i.e. 16 rays of identical
@@ -385,7 +393,9 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     const int seg_y = (int)blockIdx.y - row0;
     const int count = FIRST ? 0 : (int)P.count[cur][seg_y];
     if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
-    trace_group<FIRST, STATS, SPILL, CULL>(P, pass, seg_y, (int)blockIdx.x, count, lds_stack, (int)gridDim.x);
+    const PoseArgs* pa = nullptr;
+    if constexpr (FIRST) pa = &poses;
+    trace_group<FIRST, STATS, SPILL, CULL>(P, pass, seg_y, (int)blockIdx.x, count, lds_stack, (int)gridDim.x, pa);
 }
 
 // The remainder of the segments whose count exceeds the tightened row of this pass (GridHint, rr_device.h): launched
@@ -631,7 +641,7 @@ __global__ __launch_bounds__(64) void k_shade(const Params P, const int pass)
         const V3 e1 = { tb.x, tb.y, tb.z }, e2 = { tc.x, tc.y, tc.z };
 
         Quat q_am; V3 t_am;
-        azimuth_frame(P, seg, q_am, t_am);
+        azimuth_frame<false>(P, nullptr, seg, q_am, t_am);
         // rmagine: geometric normal, normalised, rotated into the sensor frame,
         // flipped to oppose the ray; RadarCPU.cpp:248 normalises once more
         V3 nint = v_normalize(v_cross(e1, e2));
@@ -1391,7 +1401,7 @@ void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStr
                                    reinterpret_cast<TriRec*>(reinterpret_cast<float4*>(nodes) + tri_base4), n_tris);
 }
 
-void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int n_seg = (pass == 0 && P.set_mode) ? P.n_groups * P.n_loc : P.n_seg;
     // pass 0: one flat sequence of n_seg x n_beam rays; later passes: a row of blocks per segment
@@ -1418,10 +1428,11 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     const bool spill = P.spill_depth > 0;
 // hipExtLaunchKernelGGL: the optional events take the dispatch's own begin/end timestamps (what
     // rocprofv3 reports), not the time the launch spent waiting for CUs held by other streams
-#define RR_LAUNCH_TRACE(F, S, X, C) hipExtLaunchKernelGGL((k_trace<F, S, X, C>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass)
+#define RR_LAUNCH_TRACE0(S, X) hipExtLaunchKernelGGL((k_trace<true, S, X, false>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass, *poses)
+#define RR_LAUNCH_TRACE(F, S, X, C) hipExtLaunchKernelGGL((k_trace<F, S, X, C>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass, NoPoses{})
     if (pass == 0) {
-        if (stats) { if (spill) RR_LAUNCH_TRACE(true, true, true, false); else RR_LAUNCH_TRACE(true, true, false, false); }
-        else       { if (spill) RR_LAUNCH_TRACE(true, false, true, false); else RR_LAUNCH_TRACE(true, false, false, false); }
+        if (stats) { if (spill) RR_LAUNCH_TRACE0(true, true); else RR_LAUNCH_TRACE0(true, false); }
+        else       { if (spill) RR_LAUNCH_TRACE0(false, true); else RR_LAUNCH_TRACE0(false, false); }
     } else if (cull) {
         if (stats) { if (spill) RR_LAUNCH_TRACE(false, true, true, true); else RR_LAUNCH_TRACE(false, true, false, true); }
         else       { if (spill) RR_LAUNCH_TRACE(false, false, true, true); else RR_LAUNCH_TRACE(false, false, false, true); }
@@ -1430,6 +1441,7 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
         else       { if (spill) RR_LAUNCH_TRACE(false, false, true, false); else RR_LAUNCH_TRACE(false, false, false, false); }
     }
 #undef RR_LAUNCH_TRACE
+#undef RR_LAUNCH_TRACE0
     if (pass > 0 && pass < kMaxPasses && P.tight_groups[pass]) {     // host guarantees: no statistics build, no spill path
         const dim3 rgrid(128);
         if (cull) hipLaunchKernelGGL((k_trace_repair<true>), rgrid, block, lds, s, Pl, pass);
@@ -1437,18 +1449,11 @@ void launch_trace(const Params& P, int pass, bool stats, hipStream_t s, hipEvent
     }
 }
 
-// first node of a replayed launch graph: the call's poses, passed by value, into the lane's pose table -- the ONE node whose
-// parameters change from replay to replay (hipGraphExecKernelNodeSetParams)
-__global__ void k_set_poses(const PoseArgs a, float* table)      // table: rows of 8 floats (q.xyzw, t.xyz, 0)
-{
-    const int i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i < 8 * a.n) table[i] = (i & 7) < 7 ? a.p[i >> 3][i & 7] : 0.0f;
-}
-void* set_poses_kernel() { return (void*)k_set_poses; }
-void launch_set_poses(const PoseArgs& a, float* table, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_set_poses, dim3(1), dim3(512), 0, s, a, table);
-}
+// the pass-0 trace kernel of the plain build (no statistics): the node of a replayed launch graph whose parameters change from
+// replay to replay -- (Params, pass, PoseArgs) -- see rr_api.hip: run_frame
+void* trace0_kernel(bool spill) { return spill ? (void*)k_trace<true, false, true, false> : (void*)k_trace<true, false, false, false>; }
+// ... and the Params bytes launch_trace hands that kernel
+Params trace0_params(const Params& P) { Params Pl = P; Pl.copy_blocks = 0; return Pl; }
 
 void launch_shade(const Params& P, int pass, hipStream_t s)
 {

@@ -1,14 +1,10 @@
 #!/bin/bash
-# A/B of two builds of the library over the bench workloads: tools/ab_lib.sh <other .so> [workloads...]
-# (the in-tree library is "new", the given one "base"; alternating runs, 60 steps each)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-other=$1; shift
-wls=${@:-target_10M_400x200_4pass config3_1M_400x200_4pass config2_100k_400x200_1pass}
-for w in $wls; do for v in new base new base; do
-  if [ $v = base ]; then export RADARAYS_MI355_LIB=$other; else unset RADARAYS_MI355_LIB; fi
-  python3 $R/bench.py --workload $w --steps 60 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']; print('$w $v', d['value'], 'alone', r['isolated']['avg_launch_us'], 'live', r['avg_launch_us'])
-"; done; done
+# GPU box helper: alternating A/B of two builds of the library (ab_libs/libradarays_{old,new}.so)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; mkdir -p gpurun_out
+rounds=${1:-3}; shift
+W=${@:-target_10M_400x200_4pass}
+for w in $W; do for i in $(seq $rounds); do for v in old new; do
+  export RADARAYS_MI355_LIB=$R/ab_libs/libradarays_$v.so
+  timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 60 --warmup 5 --workload $w > gpurun_out/ablib_${v}_$w.log 2>&1
+  echo "lib=$v $w $(grep -o "\"value\": [0-9.]*\|\"avg_launch_us\": [0-9.]*\|\"hbm_resident\": [0-9.]*" gpurun_out/ablib_${v}_$w.log | tr '\n' ' ')"
+done; done; done
