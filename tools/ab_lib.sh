@@ -1,5 +1,10 @@
 #!/bin/bash
-# GPU box helper: alternating A/B of two builds of the library (ab_libs/libradarays_{old,new}.so)
+# GPU box helper: alternating A/B of two builds of the library (ab_libs/libradarays_{old,new}.so, bench.py picks the one
+# RADARAYS_MI355_LIB names).  Before the gpurun call, in the container:
+#   git archive <old rev> radarays_ros_amd/csrc include | tar -x -C /tmp/old && make -C /tmp/old/radarays_ros_amd/csrc
+#   mkdir -p ab_libs && cp /tmp/old/radarays_ros_amd/libradarays_mi355.so ab_libs/libradarays_old.so
+#   cp radarays_ros_amd/libradarays_mi355.so ab_libs/libradarays_new.so        (*.so is git-ignored; remove ab_libs afterwards)
+# usage: tools/ab_lib.sh rounds [workloads...]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; mkdir -p gpurun_out
 rounds=${1:-3}; shift
 W=${@:-target_10M_400x200_4pass}
