@@ -74,6 +74,25 @@ VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 2.0
 PREWARM_S = 0.3
 
 
+def prefer_system_hip_runtime(world):
+    """RR_BENCH_SYSTEM_HIP=1, N = 1: load the image's HIP runtime (/opt/rocm/lib/libamdhip64.so.7, ROCm 7.2 -- what the
+    library is built and linked against, and what a C++ caller such as the reference's node runs on) into the global
+    symbol scope BEFORE torch, so that it, not the ROCm 7.0.2 runtime bundled inside the torch wheel, serves this
+    process.  Why it matters: the bundled runtime carries every hipMemcpyAsync to page-locked host memory as a blit
+    KERNEL (`__amd_rocclr_copyBuffer`, competing with the simulation's kernels for the CUs), the system runtime as an SDMA
+    transfer (54 GB/s beside a chip-filling kernel, which it slows by 0.5 %: tools/d2h_engine.hip, tools/d2h_py.py).
+    N > 1 keeps torch's own runtime: its bundled RCCL has only ever been run with that one.  Returns what is in force."""
+    path = "/opt/rocm/lib/libamdhip64.so.7"
+    if os.environ.get("RR_BENCH_SYSTEM_HIP", "0") != "1" or world != 1 or "torch" in sys.modules or not os.path.exists(path):
+        return "torch wheel (bundled)"
+    import ctypes
+    try:
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return "torch wheel (bundled)"
+    return path
+
+
 def algorithmic_bytes_per_wave_pass(n_tris):
     """structure-independent floor D*64 + 4*48 + 132 with
     D = ceil(log2(T/4)) BVH levels, 4 triangles tested, 132 B of wave state."""
@@ -230,6 +249,7 @@ def main():
     if world != args.gpus:
         args.gpus = world
 
+    runtime = prefer_system_hip_runtime(world)
     import torch
     import torch.distributed as dist
     from radarays_ros_amd import native, params, scenes
@@ -643,6 +663,7 @@ def main():
                        "frames_per_step": fps, "frames_per_batch": fpb, "batches_per_step": bps,
                        "images": "delivered to page-locked host memory; timed through the last D2H copy (SURVEY §8d bracket = the reference's stopwatch, RadarCPU.cpp:147-550)",
                        "d2h_GBps": round(img_per_s * cfg.n_cells * params.N_ANGLES / 1e9, 3),
+                       "hip_runtime": runtime,
                        "sharding": ("single GPU" if world == 1 else
                                     "azimuth columns x%d, 1 frame/batch + 1 all-gather" % world if args.strong else
                                     "azimuth columns x%d, %d frames/batch, 1 all_to_all/batch (frame f -> rank f)" % (world, fpb))},

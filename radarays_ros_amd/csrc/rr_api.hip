@@ -1367,7 +1367,12 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
 {
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
-    for (Lane& L : c->lanes) {
+    // oldest batch first (lanes are handed out round robin: the next one to be used holds the oldest batch): its images leave
+    // while the younger batches still render, and only the youngest batch's copy is left when the kernels are done -- in lane
+    // order the youngest batch may come first, and the copies of all the others then queue up behind the end of the run
+    const size_t nl = c->lanes.size();
+    for (size_t k = 0; k < nl; k++) {
+        Lane& L = c->lanes[(c->next_lane + k) % nl];
         if (L.deferred && (h_imgs_u8 == nullptr || L.def_dst == h_imgs_u8)) { int rc = flush_deferred(c, L); if (rc) return rc; }
         for (Lane::CopyRec& r : L.rec)
             if (r.pending && (h_imgs_u8 == nullptr || r.dst == h_imgs_u8)) {
