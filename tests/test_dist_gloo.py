@@ -276,3 +276,16 @@ def test_bench_n1_reference_reads_profiles():
     r = bench.n1_reference("target_10M_400x200_4pass")
     assert r is not None and r["value"] > 1000 and r["source"].startswith("profiles/")
     assert bench.n1_reference("no_such_workload") is None
+
+
+def test_bench_keeps_torchs_runtime_unless_asked_and_for_n_above_one(monkeypatch):
+    """bench.py's RR_BENCH_SYSTEM_HIP switch (which engine copies): off by default, never for N > 1, never
+    once torch is in the process (the runtime that was loaded first serves the process)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    import torch  # noqa: F401  (as in every test process)
+    monkeypatch.delenv("RR_BENCH_SYSTEM_HIP", raising=False)
+    assert bench.prefer_system_hip_runtime(1).startswith("torch wheel")
+    monkeypatch.setenv("RR_BENCH_SYSTEM_HIP", "1")
+    assert bench.prefer_system_hip_runtime(8).startswith("torch wheel")
+    assert bench.prefer_system_hip_runtime(1).startswith("torch wheel")      # torch is already imported here
