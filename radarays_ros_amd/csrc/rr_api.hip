@@ -3,6 +3,7 @@
 // runs the gfx950 kernels of rr_kernels.hip or fails with an error string.
 #include "../../include/radarays_mi355.h"
 #include "rr_device.h"
+#include "rr_hostprof.h"
 
 #include <algorithm>
 #include <cmath>
@@ -670,6 +671,11 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
             uint32_t h = 0;
             for (const Lane& o : c->lanes) if (o.h_hist && o.hist_gen == c->hist_gen) h = std::max(h, o.h_hist[pass]);
             long row = h ? std::min<long>(full, ((long)h + (long)h / 16 + 32 + 15) / 16) : full;
+            // an ODD number of workgroups per row: the hardware deals workgroups out to the 8 XCDs round robin in flat order
+            // (y * row + x), so with a row length that shares a factor with 8 the same x always lands on the same XCDs -- and the
+            // tail of every row (few or no live rays) always on the same ones.  Rows rounded to a multiple of four: 435 -> 457 us
+            // per launch alone, -2.4 % images/s on the target (measured by accident, DESIGN_EXPERIMENTS.md)
+            row |= 1;
             if (c->tight_force) row = std::min<long>(full, c->tight_force);
             P.tight_groups[pass] = (row < full && row < 65535) ? (unsigned short)row : 0;
         }
@@ -770,15 +776,16 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
             void* args[3] = { (void*)&fg->pose_P, (void*)&pass0, (void*)&pa };
             hipKernelNodeParams kp = fg->pose_kp;
             kp.kernelParams = args; kp.extra = nullptr;
-            hipError_t e = hipGraphExecKernelNodeSetParams(fg->ge, fg->pose_node, &kp);
-            if (e == hipSuccess) e = hipGraphLaunch(fg->ge, s);
+            hipError_t e;
+            { HostProfScope hp(3, "ctx:   graph: set the poses"); e = hipGraphExecKernelNodeSetParams(fg->ge, fg->pose_node, &kp); }
+            { HostProfScope hp(4, "ctx:   graph: launch"); if (e == hipSuccess) e = hipGraphLaunch(fg->ge, s); }
             if (e != hipSuccess) return fail(c, -100, std::string("launch graph replay: ") + hipGetErrorString(e));
             c->graph_replays++;
             return 0;
         }
         fg->hits++;
     }
-    { const int rcq = enqueue(P); if (rcq) return rcq; }
+    { HostProfScope hp(5, "ctx:   chain issued kernel by kernel"); const int rcq = enqueue(P); if (rcq) return rcq; }
     RR_HIP(c, hipGetLastError());
     return 0;
 }
@@ -1222,9 +1229,12 @@ int rr_simulate_batch_columns_device(rr_ctx* c, const float* poses, int n_frames
     Lane& L = c->lanes[li];
     { int rcf = flush_deferred(c, L); if (rcf) return rcf; }   // images a host-delivery batch left on this lane
     c->last_lane = li;
-    if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
-    rc = run_frame(c, L, poses, az_begin, az_end, d_cols_u8, nullptr, s, n_frames); if (rc) return rc;
-    RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+    { HostProfScope hp(0, "ctx: wait for the lane's event");
+      if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0)); }
+    { HostProfScope hp(1, "ctx: run_frame");
+      rc = run_frame(c, L, poses, az_begin, az_end, d_cols_u8, nullptr, s, n_frames); if (rc) return rc; }
+    { HostProfScope hp(2, "ctx: record the lane's event");
+      RR_HIP(c, hipEventRecord(L.ev_consumed, s)); }
     L.pending_consume = true;
     return 0;
 }

@@ -1414,8 +1414,12 @@ void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, 
     // ... and since round 5 the row is as long as earlier batches needed (GridHint): tight_groups[pass], 0 = the bound
     const unsigned row = (pass > 0 && pass < kMaxPasses && P.tight_groups[pass]) ? (unsigned)P.tight_groups[pass]
                                                                                : (unsigned)((bound + kRaysPerBlock - 1) / kRaysPerBlock);
+    // (an odd row length deals the rows' workgroups evenly over the 8 XCDs, see run_frame; the extra workgroup of a full row
+    // exits on its segment's count.  Not on the spill path, whose columns are laid out for the bound)
+    const bool tightened = pass > 0 && pass < kMaxPasses && P.tight_groups[pass];     // (the host keeps tightened rows odd itself)
+    const unsigned row_odd = (pass > 0 && P.spill_depth == 0 && !tightened) ? (row | 1u) : row;
     dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + (kTraceThreads / 64) - 1) / (kTraceThreads / 64)))
-                          : dim3(row, n_seg + (P.copy_blocks > 0 ? 1 : 0));
+                          : dim3(row_odd, n_seg + (P.copy_blocks > 0 ? 1 : 0));
     Params Pl = P;
     if (pass == 0) Pl.copy_blocks = 0;
     else Pl.copy_blocks = std::min<int>(P.copy_blocks, (int)grid.x);      // the copy's workgroups are the first of row 0

@@ -15,6 +15,7 @@
 // rr_create_multi() fails with a clear message where it is missing.  Built on the public entry points of
 // radarays_mi355.h only.
 #include "../../include/radarays_mi355.h"
+#include "rr_hostprof.h"
 
 #include <hip/hip_runtime.h>
 
@@ -434,7 +435,8 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     const int A = m->cfg.n_angles; const size_t C = (size_t)m->cfg.n_cells;
     MultiSlot& S = m->slots[m->next_slot];
     m->next_slot = (m->next_slot + 1) % m->slots.size();
-    { const int rc = wait_slot(m, S); if (rc) return rc; }        // the batch that used this slot's buffers last
+    rr::HostProfScope hp_all(8, "multi: whole call");
+    { rr::HostProfScope hp(9, "multi: wait for the slot"); const int rc = wait_slot(m, S); if (rc) return rc; }        // the batch that used this slot's buffers last
     const auto dev_msg = [&](int i) { return std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rr_last_error(m->ctx[(size_t)i]); };
     if (n == 1 && !m->self_rccl) {
         // one device: no collective; the images take the ctx's own host delivery (deferred, trickled out by the next
@@ -466,11 +468,11 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
         int rc = 0;
         if (he == hipSuccess && nl > 0) {
             rr_ctx* c = m->ctx[(size_t)i];
-            rc = rr_simulate_batch_columns_device(c, poses, n_frames, b[(size_t)i], e[(size_t)i], S.block[(size_t)i].p, S.streams[(size_t)i]);
-            if (!rc) rc = rr_peek_error_bits_async(c, &S.h_bits[i], S.streams[(size_t)i]);
+            { rr::HostProfScope hp(10, "multi: device entry: render"); rc = rr_simulate_batch_columns_device(c, poses, n_frames, b[(size_t)i], e[(size_t)i], S.block[(size_t)i].p, S.streams[(size_t)i]); }
+            { rr::HostProfScope hp(11, "multi: device entry: error bits"); if (!rc) rc = rr_peek_error_bits_async(c, &S.h_bits[i], S.streams[(size_t)i]); }
             if (rc) return rc;
         }
-        if (he == hipSuccess) he = hipEventRecord(S.ev_block[(size_t)i], S.streams[(size_t)i]);
+        { rr::HostProfScope hp(12, "multi: device entry: block event"); if (he == hipSuccess) he = hipEventRecord(S.ev_block[(size_t)i], S.streams[(size_t)i]); }
         if (he != hipSuccess) { hip_err[(size_t)i] = hipGetErrorString(he); return -100; }
         return 0;
     };
@@ -496,6 +498,7 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     //    every version, so it is one group of send / recv pairs along rr_multi_plan: equal blocks travel as one piece
     //    per device into the layout [device][frame][n_loc][n_cells], ragged ones frame by frame into
     //    [frame][n_angles][n_cells]; the root's own block is a device-to-device copy on its stream
+    rr::HostProfScope hp_root(13, "multi: gather + assemble + D2H");
     RRM_TRY_HIP(hipSetDevice(m->devices[0]));
     const uint8_t* d_cols = nullptr; int n_loc = A; size_t block_stride = (size_t)A * C, frame_stride = (size_t)A * C;
     struct Piece { int dev; size_t so, ro, bytes; };
