@@ -468,7 +468,9 @@ void rr_free_mesh(rr_mesh* m);
  * RR_MULTI_THREADS (0)    1: rr_multi with several devices starts one enqueue thread per device, which issues that device's
  *                         launches of a call while the others issue theirs (off by default: on one physical device, the
  *                         only case measurable on a one-GPU box, the runtime serialises the threads and nothing is gained)
- * RR_MULTI_SLOTS (4)      batches rr_multi keeps in flight (streams + buffer sets per device, 1..8) */
+ * RR_MULTI_SLOTS (4)      batches rr_multi keeps in flight (streams + buffer sets per device, 1..8)
+ * RR_HOST_PROFILE (0)     1: where the HOST time of the batch calls goes (named scopes in rr_ctx / rr_multi, csrc/rr_hostprof.h);
+ *                         a table on stderr when the process ends (read it with RR_MULTI_THREADS=0) */
 
 #ifdef __cplusplus
 }
