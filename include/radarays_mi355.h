@@ -451,6 +451,8 @@ void rr_free_mesh(rr_mesh* m);
  * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)
  * RR_GRAPHS (1)           launch chains of pose batches captured and replayed as hipGraphs (rr_get_graph_stats); 0: kernel by kernel
  * RR_TIGHT_GRID (1)       later-pass trace rows sized by the history of earlier batches (rr_get_trace_grid); 0: the doubling bound
+ * RR_TRACE_CHUNK (16)     later-pass trace launches walk chunks of S neighbouring azimuths with the azimuth as the fast grid dimension;
+ *                         0: one grid row per azimuth (same images)
  * RR_TIGHT_FORCE (0)      n > 0: rows of n workgroups whatever the history says (tests: nearly every ray goes through the repair launch)
  * RR_STACK_LDS (64)       traversal stack entries kept in LDS (lower: exercises the HBM spill path)
  * RR_PASS0_AZ (16)        neighbouring azimuths per pass-0 wave (1, 2, 4, 8, 16)

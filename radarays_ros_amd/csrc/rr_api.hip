@@ -192,6 +192,7 @@ struct rr_ctx {
 
     bool roctx = false;
     int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
+    int seg_chunk = 16;          // later-pass trace grids in chunks of S neighbouring segments, segment-fast inside a chunk (RR_TRACE_CHUNK; 0: rows of one segment)
     int cull_pop = 1;            // k_trace's later passes drop stack entries at pop time (RR_CULL_POP=0: off; the images are the same either way)
     int copy_blocks = 8;         // workgroups (one wave each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
     int tight_grid = 1;          // later-pass trace rows sized by what earlier batches needed (RR_TIGHT_GRID=0: the doubling bound)
@@ -549,7 +550,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.spill_stride = L.spill_stride; P.stack_lds = L.stack_lds;
     P.spill_depth = std::max(0, (int)c->stack_need - L.stack_lds);
     P.pass0_az = c->pass0_az;
-    P.cull_pop = c->cull_pop;
+    P.cull_pop = c->cull_pop; P.seg_chunk = c->seg_chunk;
     P.grid_hint = L.d_hint.p; P.ovf_list = L.d_ovf_list.p; P.ovf_stride = L.ovf_stride;     // rows stay at the bound until run_frame tightens them
 }
 
@@ -857,6 +858,7 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_ROCTX") && atoi(getenv("RR_ROCTX")) != 0) c->roctx = roctx_load();
     if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
     if (getenv("RR_CULL_POP")) c->cull_pop = atoi(getenv("RR_CULL_POP")) != 0;
+    if (getenv("RR_TRACE_CHUNK")) c->seg_chunk = std::max(0, std::min(1024, atoi(getenv("RR_TRACE_CHUNK"))));
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
     if (getenv("RR_GRAPHS")) c->use_graphs = atoi(getenv("RR_GRAPHS")) != 0;
     if (getenv("RR_TIGHT_GRID")) c->tight_grid = atoi(getenv("RR_TIGHT_GRID")) != 0;

@@ -172,6 +172,11 @@ struct Params {
     // not rays -- its first copy_blocks workgroups trickle a slice of the images the lane's PREVIOUS batch left in
     // device memory to page-locked host memory, one 1-KB store per wave in flight
     const uint4* copy_src; uint4* copy_dst; unsigned long long copy_n16; int copy_blocks;
+    int trace_row;           // (set by launch_trace) row length of this launch when seg_chunk > 0
+    // later-pass k_trace, S > 0: the grid is (S, ceil(n_seg / S) * row) -- chunks of S neighbouring segments (azimuths of one
+    // frame), and inside a chunk the SEGMENT is the fast dimension: the workgroups that run at the same time hold the same trace
+    // positions of neighbouring azimuths, and a segment stays on ONE XCD (S a multiple of 8).  0: one row of the grid per segment
+    int seg_chunk;
     int cull_pop;            // later passes / rr_debug_trace: drop stack entries at pop time by their 16-bit distance bound (0: off, RR_CULL_POP=0)
     // tight later-pass trace grids (GridHint above)
     GridHint* grid_hint;     // per lane; null: off

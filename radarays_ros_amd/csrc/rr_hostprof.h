@@ -17,8 +17,7 @@ struct HostProf {
     uint64_t calls[kMax] = {};
     HostProf()
     {
-        const char* e = getenv("RR_HOST_PROFILE");
-        on = e && atoi(e) != 0;
+        on = getenv("RR_HOST_PROFILE") && atoi(getenv("RR_HOST_PROFILE")) != 0;
     }
     ~HostProf()
     {

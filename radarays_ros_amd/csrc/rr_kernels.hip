@@ -390,12 +390,20 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
         }
         return;
     }
-    const int seg_y = (int)blockIdx.y - row0;
+    int seg_y = (int)blockIdx.y - row0, gx = (int)blockIdx.x, gdim = (int)gridDim.x;
+    if (!FIRST && P.seg_chunk > 0) {
+        // chunks of S neighbouring segments; inside a chunk the segment is the fast dimension: y - row0 = chunk * row + group
+        gdim = P.trace_row;
+        const int yy = (int)blockIdx.y - row0, ch = yy / gdim;
+        gx = yy - ch * gdim;
+        seg_y = ch * P.seg_chunk + (int)blockIdx.x;
+        if (seg_y >= P.n_seg) return;
+    }
     const int count = FIRST ? 0 : (int)P.count[cur][seg_y];
-    if (!FIRST && (int)(blockIdx.x * kRaysPerBlock) >= count) return;
+    if (!FIRST && gx * kRaysPerBlock >= count) return;
     const PoseArgs* pa = nullptr;
     if constexpr (FIRST) pa = &poses;
-    trace_group<FIRST, STATS, SPILL, CULL>(P, pass, seg_y, (int)blockIdx.x, count, lds_stack, (int)gridDim.x, pa);
+    trace_group<FIRST, STATS, SPILL, CULL>(P, pass, seg_y, gx, count, lds_stack, gdim, pa);
 }
 
 // The remainder of the segments whose count exceeds the tightened row of this pass (GridHint, rr_device.h): launched
@@ -1421,6 +1429,11 @@ void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, 
     dim3 grid = pass == 0 ? dim3((unsigned)((waves0 + (kTraceThreads / 64) - 1) / (kTraceThreads / 64)))
                           : dim3(row_odd, n_seg + (P.copy_blocks > 0 ? 1 : 0));
     Params Pl = P;
+    if (pass > 0 && P.seg_chunk > 0) {
+        const unsigned S = (unsigned)P.seg_chunk, n_chunks = ((unsigned)n_seg + S - 1) / S;
+        if ((size_t)n_chunks * row + 1 <= 65535) { grid = dim3(S, n_chunks * row + (P.copy_blocks > 0 ? 1 : 0)); Pl.trace_row = (int)row; }
+        else Pl.seg_chunk = 0;        // (beyond the grid's y limit: the plain layout)
+    }
     if (pass == 0) Pl.copy_blocks = 0;
     else Pl.copy_blocks = std::min<int>(P.copy_blocks, (int)grid.x);      // the copy's workgroups are the first of row 0
     dim3 block(kTraceThreads);

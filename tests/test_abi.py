@@ -163,7 +163,7 @@ def test_environment_switches_are_documented():
     import re
     csrc = os.path.join(ROOT, "radarays_ros_amd", "csrc")
     used = set()
-    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")):
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")):
         used |= set(re.findall(r'getenv\("(RR_[A-Z0-9_]+)"\)', open(f).read()))
     text = open(os.path.join(ROOT, "include", "radarays_mi355.h")).read()
     block = text[text.index("---- environment switches"):]
