@@ -470,3 +470,45 @@ def test_launch_graphs_replay_identical_images_and_are_dropped_on_any_change(nat
         with pytest.raises(native_lib.RRError, match="capacity"):
             c.synchronize(st)
     c.close(); c0.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Later-pass trace grids in chunks of 16 azimuths (RR_TRACE_CHUNK): a launch shape, never a different image
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_chunked_trace_grid_is_only_a_launch_shape(native_lib, monkeypatch):
+    """The later passes walk chunks of S neighbouring segments with the segment as the fast grid dimension.  Same bytes as one
+    grid row per segment (RR_TRACE_CHUNK=0) for (1) a 64-frame batch of a 4-pass config -- 25,600 segments: the chunked grid of
+    the late passes would exceed the 65,535 rows a grid may have, so those launches fall back to the plain layout while
+    the early ones are chunked; (2) an azimuth block whose segment count is not a multiple of the chunk (7 columns x 3
+    frames: the last chunk is ragged); (3) S = 64 and S = 8."""
+    import torch
+    s = scenes.heightfield_room(64, n_buildings=120, seed=5)
+    from common import materials_for
+    cfg = params.kaist_preset(n_reflections=4, n_samples=100, ambient_noise=0)
+    z = scenes.default_pose(s["name"])[6]
+    poses64 = [scenes.yaw_pose(-30.0 + 1.1 * k, 12.0 - 0.4 * k, z + 1.0 + 0.05 * k, 0.1 * k) for k in range(64)]
+
+    def render(chunk):
+        monkeypatch.setenv("RR_TRACE_CHUNK", str(chunk))
+        c = native_lib.Context(0)
+        c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+        c.set_materials(materials_for(s), s["object_materials"], 0)
+        c.set_config(cfg)
+        c.set_beam_samples(golden_beams(100))
+        big = [_batch(c, poses64, cfg) for _ in range(2)]                   # second call: tightened rows
+        cols = torch.zeros((3, 7, cfg.n_cells), dtype=torch.uint8, device="cuda:0")
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            c.simulate_batch_columns_device(poses64[:3], 100, 107, cols.data_ptr(), st)
+            torch.cuda.synchronize()
+        c.synchronize()
+        out = big, cols.cpu().numpy().copy()
+        c.close()
+        return out
+    monkeypatch.delenv("RR_TIGHT_FORCE", raising=False)
+    (w0, w1), wc = render(0)
+    assert np.array_equal(w0, w1) and w0.any() and wc.any()
+    for chunk in (16, 64, 8):
+        (g0, g1), gc = render(chunk)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w0) and np.array_equal(gc, wc), chunk
