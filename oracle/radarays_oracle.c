@@ -830,6 +830,8 @@ static int simulate_impl(const orc_scene* scene,
      * as { int32 azimuth, int32 pass, float o[3], float d[3], uint32 parent << 1 | refraction, uint32 material } in
      * map coordinates (parent = index of the parent wave among the rays of the previous pass of that azimuth) */
     FILE* raylog = getenv("ORC_RAYLOG") ? fopen(getenv("ORC_RAYLOG"), "ab") : NULL;
+    /* tooling only (tools/xcd_rows.py): ORC_COUNTS=<file> appends "azimuth pass waves" for every pass of every azimuth */
+    FILE* cntlog = getenv("ORC_COUNTS") ? fopen(getenv("ORC_COUNTS"), "a") : NULL;
 
     const double t_start = now_s();   /* RadarCPU.cpp:147-148 */
 
@@ -885,6 +887,10 @@ static int simulate_impl(const orc_scene* scene,
         for (int pass_id = 0; pass_id < cfg->n_reflections; pass_id++)   /* :220 */
         {
             waves_new.n = 0;
+            if (cntlog) {
+                #pragma omp critical(cntlog)
+                fprintf(cntlog, "%d %d %zu\n", angle_id, pass_id, waves.n);
+            }
             for (size_t i = 0; i < waves.n; i++)   /* :243 */
             {
                 wave_t wave = waves.p[i];
@@ -1078,6 +1084,7 @@ static int simulate_impl(const orc_scene* scene,
 
     const double t_stop = now_s();   /* :550 */
     if (raylog) fclose(raylog);
+    if (cntlog) fclose(cntlog);
     free(w);
     if (stats) {
         stats->wave_passes = tot_wp; stats->hits = tot_hits; stats->signals = tot_sig; stats->near_threshold = tot_near;
