@@ -156,6 +156,49 @@ def visible_gpus():
     return n
 
 
+_JSON_OUT = None          # where the ONE line goes once main() has moved file descriptor 1 out of the way
+
+
+def _errdir():
+    """Where the ranks of one launch leave their failure records: given by the self-launching parent, else keyed by the
+    launcher's pid (the ranks of a torch.distributed.run share their parent)."""
+    import tempfile
+    d = os.environ.get("RR_BENCH_ERRDIR") or os.path.join(tempfile.gettempdir(), "rr_bench_err_%d" % os.getppid())
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def error_line(world, rank, message, extra=None):
+    """The ONE line a failed run prints instead of a result (same keys a reader of the result line looks at first)."""
+    out = {"metric": "polar images/sec (400 az x 3424 bins)", "value": None, "unit": "images/s", "n_gpus": int(world),
+           "error": message, "failing_rank": rank}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def report_failure(exc):
+    """A rank failed: leave a record for the launcher and -- the first rank to get here only -- print the error line.  The
+    message carries what the failing layer said: RRError texts are rr_last_error / rr_multi_last_error, torch.distributed
+    errors carry RCCL's own string."""
+    import traceback
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    msg = "%s: %s" % (type(exc).__name__, exc)
+    d = _errdir()
+    with open(os.path.join(d, "rank_%d.json" % rank), "w") as f:
+        json.dump({"rank": rank, "error": msg, "traceback": traceback.format_exc()[-4000:]}, f)
+    try:
+        os.close(os.open(os.path.join(d, "printed"), os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+    except FileExistsError:
+        return
+    line = json.dumps(error_line(world, rank, msg)) + "\n"
+    if _JSON_OUT is not None:
+        _JSON_OUT.write(line); _JSON_OUT.flush()
+    else:
+        sys.stdout.write(line); sys.stdout.flush()
+
+
 def self_launch(n_gpus):
     """Runs this very command under `python -m torch.distributed.run` with one rank per GPU (child process; its
     rank 0 prints the JSON line on our stdout) and returns its exit code.  Fewer GPUs than asked for: one clear
@@ -173,9 +216,27 @@ def self_launch(n_gpus):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    import shutil
+    import tempfile
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
-    return subprocess.call(cmd, env=env)
+    errdir = tempfile.mkdtemp(prefix="rr_bench_err_")
+    env["RR_BENCH_ERRDIR"] = errdir
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0 and not os.path.exists(os.path.join(errdir, "printed")):
+        # no rank got as far as reporting (killed by a signal, a crash below python): the launcher's code is all there is
+        recs = []
+        for f in sorted(os.listdir(errdir)):
+            if f.startswith("rank_"):
+                try:
+                    recs.append(json.load(open(os.path.join(errdir, f))))
+                except (OSError, ValueError):
+                    pass
+        print(json.dumps(error_line(n_gpus, recs[0]["rank"] if recs else None,
+                                    recs[0]["error"] if recs else "a rank ended without a python exception (launcher exit code %d)" % rc,
+                                    {"launcher_rc": rc})), flush=True)
+    shutil.rmtree(errdir, ignore_errors=True)
+    return rc
 
 
 def rccl_block(rank, world, device_desc, collective, bytes_per_collective, own_images_per_s, group=None):
@@ -214,7 +275,58 @@ def n1_reference(workload):
     return None
 
 
-def main():
+# ---- CPU dry run of the N > 1 control flow (tests/test_dist_gloo.py; never on a GPU box) --------------------------------
+# RR_BENCH_DRYRUN=1 + TEST_HOOKS = {"context": factory(local_rank) -> object with native.Context's methods}: main() runs on
+# the gloo backend with CPU tensors and this stand-in for the few torch.cuda calls it makes, so that the rank / barrier /
+# all_reduce / rccl-block / line-assembly code of an 8-GPU run is EXECUTED before the first such run exists.  The numbers it
+# prints mean nothing; the product path is untouched (the flag is refused when a HIP device is visible).
+TEST_HOOKS = None
+
+
+class _CpuCuda:
+    class Event:
+        def __init__(self, enable_timing=False):
+            self.t = None
+
+        def record(self, stream=None):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return 1e3 * (other.t - self.t)
+
+    class Stream:
+        cuda_stream = None
+
+        def __init__(self, device=None):
+            pass
+
+        def synchronize(self):
+            pass
+
+    @staticmethod
+    def synchronize():
+        pass
+
+    @staticmethod
+    def current_stream():
+        return _CpuCuda.Stream()
+
+    @staticmethod
+    def set_device(i):
+        pass
+
+    @staticmethod
+    def is_available():
+        return True
+
+    @staticmethod
+    def get_device_properties(i):
+        class P:
+            name = "cpu dry run"
+        return P()
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -232,7 +344,7 @@ def main():
     ap.add_argument("--frames-per-rank", type=int, default=8,
                     help="frames each GPU finishes per batch (one set of launches); a batch = N x this many frames")
     ap.add_argument("--batches-per-step", type=int, default=2, help="batches per step (default: 2 x 8 = the 16-pose trajectory)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,7 +355,8 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     # stdout carries ONE line, the JSON line: whatever else writes to file descriptor 1 from here on -- RCCL prints a
     # five-line version banner there when a communicator is made, from C, flushed at exit, i.e. AFTER the line -- goes to stderr
-    json_out = os.fdopen(os.dup(1), "w")
+    global _JSON_OUT
+    json_out = _JSON_OUT = os.fdopen(os.dup(1), "w")
     sys.stdout.flush()
     os.dup2(2, 1)
     if world != args.gpus:
@@ -256,15 +369,22 @@ def main():
     from radarays_ros_amd.dist import AzimuthShard
     from radarays_ros_amd.fixtures import golden_beams, materials_for
 
-    if not torch.cuda.is_available():
+    dry = os.environ.get("RR_BENCH_DRYRUN", "0") == "1" and TEST_HOOKS is not None
+    if dry and torch.cuda.is_available():
+        raise SystemExit("bench.py: RR_BENCH_DRYRUN is a CPU-only test switch")
+    tc = _CpuCuda if dry else torch.cuda
+    if not tc.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    tc.set_device(local_rank)
     if world > 1 or args.force_slots:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     scene_id, n_pass, n_rays = WORKLOADS[args.workload]
     scene = scenes.config_scene(scene_id)
@@ -275,7 +395,7 @@ def main():
     noise = (np.random.RandomState(7).uniform(0, 1, 16 * params.N_ANGLES) * 1000.0).astype(np.float32)
     poses = scenes.trajectory(16, scene["name"])
 
-    ctx = native.Context(local_rank)
+    ctx = TEST_HOOKS["context"](local_rank) if dry else native.Context(local_rank)
     ctx.set_mesh(scene["verts"], scene["faces"], scene["face_object_id"])
     ctx.set_materials(mats, scene["object_materials"], 0)
     ctx.set_config(cfg, params.N_ANGLES, brdf_model=1 if scene_id == 5 else 0)
@@ -283,7 +403,7 @@ def main():
     ctx.set_noise_offsets(noise)
     n_tris = len(scene["faces"])
 
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     # the timed steps end with every image in HOST memory (the reference's stopwatch bracket).  N = 1: the
     # library's own host delivery (rr_simulate_batch_host_async); N > 1: every rank delivers the frames it assembled
     host_mode = world == 1 and not args.force_slots
@@ -301,7 +421,7 @@ def main():
 
     if host_mode:
         F = args.frames_per_rank
-        h_streams = [torch.cuda.Stream(device=dev) for _ in range(args.slots)]
+        h_streams = [tc.Stream(device=dev) for _ in range(args.slots)]
         # a ring of host buffers twice as deep as the batches in flight: the consumer side (rr_wait_host before a
         # buffer is handed out again) then never stalls the producer
         hosts = [native.HostImages((F, cfg.n_cells, params.N_ANGLES)) for _ in range(2 * args.slots)]
@@ -334,35 +454,35 @@ def main():
         if collective and world > 1:
             for k in range(4):
                 fn(k)
-            torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            tc.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             more = int(math.ceil(seconds / max(float(t.item()) / 4.0, 1e-6))) - 4
             for k in range(4, 4 + max(more, 0)):
                 fn(k)
-            torch.cuda.synchronize()
+            tc.synchronize()
             return 4 + max(more, 0)
         while True:
             fn(k); k += 1
             if k % 4 == 0:
-                torch.cuda.synchronize()
+                tc.synchronize()
                 if time.perf_counter() - t0 >= seconds:
                     return k
 
     for k in range(args.warmup):
         step(k)
-    torch.cuda.synchronize()
+    tc.synchronize()
     # ---- instrumentation, all of it outside (and before) the timed region ---------------------------------
     # one batch: wave-pass count of this workload
     shard.step([poses[f % len(poses)] for f in range(fpb)], None)
-    torch.cuda.synchronize()
+    tc.synchronize()
     st = ctx.stats()
     wave_passes_batch_rank = st["wave_passes"]
     assert st["overflow"] == 0, st
     # one batch with the counting build of k_trace: measured node / triangle fetches per wave-pass
     ctx.set_stats_mode(True)
     shard.step([poses[f % len(poses)] for f in range(fpb)], None)
-    torch.cuda.synchronize()
+    tc.synchronize()
     st2 = ctx.stats()
     shape = ctx.traversal_shape()
     ctx.set_stats_mode(False)
@@ -375,33 +495,51 @@ def main():
         ctx.kernel_time(name, reset=True)
     for k in range(6):
         shard.step([poses[(k * fpb + f) % len(poses)] for f in range(fpb)], None)
-        torch.cuda.synchronize()
+        tc.synchronize()
     iso = {name: ctx.kernel_time(name, reset=True) for name in KERNEL_LABEL}      # (total ms, launches)
     ctx.set_timing_mode(0)
     dominant = max(iso, key=lambda n: iso[n][0])
     # ---- the timed region: exactly `steps` steps between two synchronisation points ------------------------
     # (timing mode 2: pooled hipExtLaunchKernel events around the k_trace launches only, on the launch stream)
-    done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    ctx.reserve_timing_events(2 * n_pass * bps * args.steps + 64)
+    done = [tc.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ctx.reserve_timing_events(4 * n_pass * bps * args.steps + 64)
     prewarm(step_main, collective=True)
-    finish_main(); torch.cuda.synchronize()
-    ctx.set_timing_mode(2)
-    ctx.kernel_time("trace", reset=True); ctx.kernel_time("trace0", reset=True)
+    finish_main(); tc.synchronize()
+    # (RR_BENCH_LIVE_TIMING=0: a diagnostic -- the timed region without the begin / end events around its k_trace launches;
+    # roofline.frac then falls back to the isolated launch time and says so)
+    live_timing = os.environ.get("RR_BENCH_LIVE_TIMING", "1") != "0"
+    ctx.set_timing_mode(2 if live_timing else 0)
+    ctx.kernel_time("trace", reset=True); ctx.kernel_time("trace0", reset=True); ctx.kernel_time("trace_repair", reset=True)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    done[0].record(torch.cuda.current_stream())
+    tc.synchronize()
+    done[0].record(tc.current_stream())
     t0 = time.perf_counter()
     for k in range(args.steps):
         step_main(k, done[k + 1])
     finish_main()                                     # ... through the last D2H copy of the last image
-    torch.cuda.synchronize()
+    tc.synchronize()
     t_own = time.perf_counter() - t0                  # this rank's own time (the line's `value` uses the slowest rank's)
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    live = {n: ctx.kernel_time(n, reset=True) for n in ("trace", "trace0")}
+    live = {n: ctx.kernel_time(n, reset=True) for n in ("trace", "trace0", "trace_repair")}
     ctx.set_timing_mode(0)
+    # ---- contention: every kernel's duration while `slots` batches share the chip (outside the timed region: stream events
+    # around every launch keep the launch graphs off and cost host time) against its duration alone (`iso` above)
+    live_all = None
+    if rank == 0 and world == 1 and not args.force_slots:
+        ctx.reserve_timing_events(2 * 8 * (n_pass * 3 + 2) * bps + 64)
+        for k in range(2):
+            step_main(k)
+        ctx.set_timing_mode(1)
+        for name in KERNEL_LABEL:
+            ctx.kernel_time(name, reset=True)
+        for k in range(6):
+            step_main(k)
+        finish_main(); tc.synchronize()
+        live_all = {name: ctx.kernel_time(name, reset=True) for name in KERNEL_LABEL}
+        ctx.set_timing_mode(0)
     # per-step times: steps overlap and may finish out of order (4 streams), so a single step has no duration of
     # its own; what is defined is the cadence -- completion times in completion order, differenced over windows of
     # `slots` completions (one window = as many steps as can be in flight)
@@ -411,10 +549,10 @@ def main():
 
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        wp = torch.tensor([wave_passes_batch_rank], dtype=torch.int64, device="cuda")
+        wp = torch.tensor([wave_passes_batch_rank], dtype=torch.int64, device=dev)
         dist.all_reduce(wp, op=dist.ReduceOp.SUM)
         wave_passes_batch = int(wp.item())
     else:
@@ -428,11 +566,11 @@ def main():
             h.close()
         # the same steps with the images left in HBM (`value` of rounds 1-4)
         prewarm(step)
-        torch.cuda.synchronize()
+        tc.synchronize()
         th0 = time.perf_counter()
         for k in range(args.steps):
             step(k)
-        torch.cuda.synchronize()
+        tc.synchronize()
         th1 = time.perf_counter()
         hbm_res = {"value": round(args.steps * fps / (th1 - th0), 2), "unit": "images/s",
                    "ms_per_step": round(1e3 * (th1 - th0) / args.steps, 4),
@@ -441,11 +579,11 @@ def main():
         one = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, 0, 1, dev, frames_per_rank=1, n_slots=args.slots)
         n1 = max(args.steps, 16)
         prewarm(lambda k: one.step([poses[k % len(poses)]], None))
-        torch.cuda.synchronize()
+        tc.synchronize()
         ts0 = time.perf_counter()
         for k in range(n1):
             one.step([poses[k % len(poses)]], None)
-        torch.cuda.synchronize()
+        tc.synchronize()
         ts1 = time.perf_counter()
         single = {"value": round(n1 / (ts1 - ts0), 2), "unit": "images/s", "frames_per_launch_set": 1,
                   "ms_per_image": round(1e3 * (ts1 - ts0) / n1, 4), "images": n1,
@@ -467,12 +605,12 @@ def main():
         # strong-scaling proxy on ONE GPU: a block of 400/N azimuth columns alone on the chip against the whole frame -- what
         # sharding ONE frame N ways can win at best (the collective and the transpose still to be added)
         blk = torch.zeros((params.N_ANGLES, cfg.n_cells), dtype=torch.uint8, device=dev)
-        s1 = torch.cuda.Stream(device=dev)
+        s1 = tc.Stream(device=dev)
 
         def block_ms(b, e, n=40):
             ts = []
             for k in range(n + 6):
-                torch.cuda.synchronize(); tq = time.perf_counter()
+                tc.synchronize(); tq = time.perf_counter()
                 ctx.simulate_columns_device(poses[k % len(poses)], b, e, blk.data_ptr(), None, s1.cuda_stream); s1.synchronize()
                 if k >= 6:
                     ts.append(1e3 * (time.perf_counter() - tq))
@@ -496,7 +634,7 @@ def main():
         wproxy = None
         Fw = args.frames_per_rank
         if Fw * 8 <= 64:
-            wstreams = [torch.cuda.Stream(device=dev) for _ in range(args.slots)]
+            wstreams = [tc.Stream(device=dev) for _ in range(args.slots)]
             wproxy = {}
             base_ms = None
             for n_sh in (1, 2, 4, 8):
@@ -517,12 +655,12 @@ def main():
                         ctx.assemble_frames_device(blocks[n % args.slots].data_ptr(), nl, Fw * nl * cfg.n_cells, Fw, nl * cfg.n_cells,
                                                    imgs_w[n % args.slots].data_ptr(), st_.cuda_stream)
                 prewarm(step_w)
-                torch.cuda.synchronize()
+                tc.synchronize()
                 tw0 = time.perf_counter()
                 n_st = max(args.steps // 2, 10)
                 for k in range(n_st):
                     step_w(k)
-                torch.cuda.synchronize()
+                tc.synchronize()
                 ms = 1e3 * (time.perf_counter() - tw0) / n_st
                 if n_sh == 1:
                     base_ms = ms
@@ -537,7 +675,7 @@ def main():
     # ---- N > 1: what a reader needs to believe RCCL saw N ranks ------------------------------------------------
     rccl = None
     if world > 1 or args.force_slots:
-        props = torch.cuda.get_device_properties(local_rank)
+        props = tc.get_device_properties(local_rank)
         bus = None
         if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
             bus = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
@@ -586,7 +724,7 @@ def main():
         if dominant in live and live[dominant][1] > 0:
             live_s = 1e-3 * live[dominant][0] / live[dominant][1]
             live_n = int(live[dominant][1])
-        else:                                               # a kernel other than k_trace dominates: isolated figure only
+        else:                                               # a kernel other than k_trace dominates (or RR_BENCH_LIVE_TIMING=0): isolated figure only
             live_s, live_n = iso_s, int(iso_n)
         wp_launch = wave_passes_batch_rank / max(n_pass, 1)  # mean wave-passes of one k_trace launch
         achieved = (insts / live_s) if (insts and live_s > 0) else None
@@ -623,6 +761,8 @@ def main():
                 "frac": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTR_S, 4),
                 "traffic": traffic,
                 "avg_launch_us": round(live_s * 1e6, 2), "launches": live_n, "batches_in_flight": int(args.slots),
+                # the k_trace_repair launch behind every tightened later-pass row has its own events: NOT inside avg_launch_us
+                "trace_repair_avg_us": (round(1e3 * live["trace_repair"][0] / live["trace_repair"][1], 2) if live.get("trace_repair", (0, 0))[1] else None),
                 "wave_instr_per_launch": insts,
                 "basis": "SQ_INSTS_VALU per launch (rocprofv3 --pmc of this command: %s) / average launch duration of the "
                          "timed region (hipExtLaunchKernel begin/end events on the launch stream); unweighted: k_trace "
@@ -646,6 +786,22 @@ def main():
                 "algorithmic_GBps": (round(wp_launch * b_wp / live_s / 1e9, 2) if dominant in ("trace", "trace0") and live_s > 0 else None),
                 "frames_per_launch": n_launch_frames,
                 "useful_issue_frac": useful}
+        contention = None
+        if live_all:
+            per_batch = {"trace0": 1, "trace": max(n_pass - 1, 0), "shade": n_pass, "scan": max(n_pass - 1, 0), "column": 1, "assemble": 1}
+            avg = lambda d, n: (d[n][0] / d[n][1]) if d[n][1] else 0.0     # noqa: E731  (ms per launch)
+            ratio = lambda n: (round(avg(live_all, n) / avg(iso, n), 2) if avg(iso, n) > 0 and avg(live_all, n) > 0 else None)   # noqa: E731
+            contention = {"batch_ms_isolated_sum": round(sum(avg(iso, n) * k for n, k in per_batch.items()), 4),
+                          "batch_ms_live": round(1e3 * elapsed / (args.steps * bps), 4),
+                          "trace_live_over_alone": ratio("trace"), "trace0_live_over_alone": ratio("trace0"),
+                          "shade_live_over_alone": ratio("shade"), "scan_live_over_alone": ratio("scan"),
+                          "column_live_over_alone": ratio("column"), "assemble_live_over_alone": ratio("assemble"),
+                          "live_us": {KERNEL_LABEL[n]: round(1e3 * avg(live_all, n), 1) for n in live_all},
+                          "alone_us": {KERNEL_LABEL[n]: round(1e3 * avg(iso, n), 1) for n in iso},
+                          "what": "batch_ms_isolated_sum = the kernels of one batch one after the other, each at its duration with ONE batch on "
+                                  "the chip; batch_ms_live = the timed region's time per batch with %d batches in flight: what running them "
+                                  "concurrently buys is the ratio of the two.  *_live_over_alone = a launch's duration (stream events "
+                                  "around it, a short region after the timed one) with %d batches sharing the chip / alone" % (args.slots, args.slots)}
         out = {
             "metric": "polar images/sec (400 az x 3424 bins)",
             "value": round(img_per_s, 2),
@@ -682,6 +838,7 @@ def main():
             "strong_scaling_proxy": proxy,
             "weak_scaling_proxy": wproxy,
             "roofline": roof,
+            "contention": contention,
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -757,4 +914,10 @@ def cpu_baseline(scene, cfg, mats, beams, noise, poses, budget_s, brdf_model=0):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:       # noqa: BLE001  one JSON line with "error" instead of a traceback only, then non-zero
+        report_failure(exc)
+        raise

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 5
+#define RR_ABI_VERSION 6
 #define RR_MAX_BATCH 64   /* frames (poses or material sets) one call renders in one set of launches */
 
 typedef struct rr_ctx rr_ctx;
@@ -220,6 +220,16 @@ int rr_wait_host(rr_ctx* ctx, const void* h_imgs_u8);
 void* rr_host_alloc(size_t bytes);
 void  rr_host_free(void* p);
 
+/* bytes of device memory -> host memory, asynchronous on `stream`, by the library's own copy kernel (one-wave workgroups,
+ * 1 KB per wave and store, a bounded number of stores outstanding per wave) when h_dst is page-locked and both pointers
+ * and the size are multiples of 16 -- else a plain hipMemcpyAsync.  Why an entry point: which engine carries a
+ * hipMemcpyAsync to page-locked memory is the choice of the HIP runtime in the caller's process (a ROCm 7.0.2 runtime
+ * launches a blit kernel per copy and reads 27-36k images/s on config 2, the image's own ROCm 7.2 uses SDMA: 39.4k);
+ * every delivery of this library (rr_simulate_batch_host_async's deferred copies, rr_wait_host's flush, the sharded step
+ * loop's flush_host) takes this route, so the delivered rate does not depend on it.  Replaces nothing in the reference
+ * (cv_bridge deep-copies m_polar_image on the host, RadarCPU.cpp:555-558). */
+int rr_copy_to_host_async(rr_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
+
 /* Assemble the mono8 image from column-major columns, applying scroll_image
  * (RadarCPU.cpp:457): d_img[c][(scroll + a) % n_angles] = d_cols[a][c].
  * Device buffers, asynchronous on `stream`. */
@@ -329,6 +339,13 @@ int rr_debug_trace(rr_ctx* ctx, const float* origs /*[n][3]*/, const float* dirs
                    float* out_t /*[n], <0 = miss*/, uint32_t* out_face /*[n]*/);
 /* BVH facts: nodes, leaf triangle records (>= faces: the host builder may cut a face by spatial splits and keeps
  * one record per part, at most twice the faces), depth, stack entries needed. */
+/* Test hook: the kernels' own Fresnel split (k_shade's fresnel_split = radar_algorithms.h:55-139; the incidence angle by acosf of
+ * the f32 dot product as k_shade forms it, the angle of total reflection by the function that fills the material table) on n
+ * independent inputs: v1 = the wave's velocity (0.3 in the frame path, RadarCPU.cpp:107-110), v2 = the material's.  Host arrays
+ * in, host arrays out; tests compare them with the oracle on the reference-derived cases of tests/golden/pyref_dense_*. */
+int rr_debug_fresnel(rr_ctx* ctx, size_t n, const float* normals /*[n][3]*/, const float* dirs /*[n][3]*/, const double* energy /*[n]*/,
+                     const double* v1 /*[n]*/, const float* v2 /*[n]*/,
+                     float* out_refl_dir /*[n][3]*/, double* out_refl_energy /*[n]*/, float* out_refr_dir /*[n][3]*/, double* out_refr_energy /*[n]*/);
 int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* depth, uint32_t* stack_need);
 /* How the later-pass trace launches are sized (round 5).  A segment holds at most n_beam * 2^pass waves in pass `pass`;
  * instead of a row of 16-ray workgroups up to that bound per segment, a row is as long as earlier batches of this context
@@ -350,7 +367,9 @@ int rr_get_graph_stats(rr_ctx* ctx, uint64_t* captures, uint64_t* replays);
  * reset!=0, measured with hipEvents on the launch stream when timing mode is
  * on; also returns the number of launches.  Used by bench.py for roofline. */
 int rr_set_timing_mode(rr_ctx* ctx, int enable /* 0 off, 1 every kernel, 2 k_trace only */);
-int rr_get_kernel_time(rr_ctx* ctx, const char* kernel /* "trace"|"shade"|"scan"|"column"|"assemble" */,
+int rr_get_kernel_time(rr_ctx* ctx, const char* kernel /* "trace0"|"trace"|"trace_repair"|"shade"|"scan"|"column"|"assemble";
+                                                            "trace" = the later-pass launches WITHOUT the k_trace_repair launch that
+                                                            follows a tightened row, which is "trace_repair" */,
                        double* total_ms, uint64_t* launches, int reset);
 
 /* every launch duration (ms) recorded for `kernel` since the last reset ("trace0" = pass 0, "trace" = later
@@ -375,6 +394,11 @@ rr_multi* rr_create_multi(const int* devices, int n_devices);    /* NULL on fail
 void rr_destroy_multi(rr_multi* m);
 const char* rr_multi_last_error(const rr_multi* m);
 int rr_multi_device_count(const rr_multi* m);
+/* the NCCL version code of the RCCL library this object's communicator was made with (ncclGetVersion: 2.27.7 -> 22707); 0: no
+ * communicator (one device, loopback) or a library that does not say.  rr_create_multi refuses a library outside [2.7, 3.0)
+ * -- the prototypes it calls through are declared by hand -- and, before the first frame, has every rank send 16 bytes to rank
+ * 0 with guard bytes behind them (the constant taken for ncclUint8 must move exactly 16). */
+int rr_multi_rccl_version(const rr_multi* m);
 rr_ctx* rr_multi_ctx(rr_multi* m, int i);                        /* the context of device i (stats, tuning) */
 /* azimuth block [*begin, *end) of `rank` among `world`: contiguous, sizes differ by at most one column */
 void rr_partition(int n_angles, int world, int rank, int* begin, int* end);
@@ -447,6 +471,12 @@ void rr_free_mesh(rr_mesh* m);
  * RR_LANES (4)            frame buffer sets = batches that can be in flight (1..8)
  * RR_STREAM_LANES (3)     lanes whose own stream rr_simulate_device rotates over
  * RR_COPY_BLOCKS (8)      one-wave workgroups of a trace launch that trickle a deferred host copy; 0: never fold
+ * RR_FLUSH_KERNEL (1)     a host copy that does not ride on a trace launch (one-pass frames, the end of a run, rr_copy_to_host_async)
+ *                         is stored by the library's own kernel when the destination is page-locked; 0: hipMemcpyAsync
+ * RR_FLUSH_BLOCKS (32)    ... its one-wave workgroups
+ * RR_FLUSH_INFLIGHT (4)   ... 1-KB stores a wave keeps outstanding (0: no limit)
+ * RR_FLUSH_THREADS (64)   ... threads per workgroup (64..1024); RR_FLUSH_NT (0): nontemporal stores
+ * RR_FLUSH_XCD (0)        ... the XCD all of them run on (PCIe-paced stores then fill the write queues of one XCD only); -1: all eight
  * RR_FOLD_MIN_BUSY (2)    other lanes that must be busy for a host copy to be folded into the next batch
  * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)
  * RR_GRAPHS (1)           launch chains of pose batches captured and replayed as hipGraphs (rr_get_graph_stats); 0: kernel by kernel

@@ -16,10 +16,11 @@
 #include <vector>
 
 namespace rr {
-void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-void launch_shade(const Params& P, int pass, hipStream_t s);
-void launch_scan(const Params& P, int pass, hipStream_t s);
-void launch_column(const Params& P, hipStream_t s);
+void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                  hipEvent_t ev_rep_start = nullptr, hipEvent_t ev_rep_stop = nullptr, bool* repair_launched = nullptr);
+void launch_shade(const Params& P, int pass, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void launch_scan(const Params& P, int pass, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void launch_column(const Params& P, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_decay_table(float* decay, int n_cells, double resolution, double energy_loss, hipStream_t s);
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,
                         int n_loc = 0, size_t block_stride = 0, int n_frames = 1, size_t frame_stride = 0);
@@ -35,6 +36,11 @@ void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStr
 void* trace0_kernel(bool spill);
 Params trace0_params(const Params& P);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
+void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int nt);
+void launch_frame_report(const Counters* cnt, const SegStats* ss, size_t n_ss, void* h_dst, hipStream_t s);
+void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s);
+void launch_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
+                          float* out_rdir, double* out_re, float* out_tdir, double* out_te, hipStream_t s);
 }  // namespace rr
 
 using namespace rr;
@@ -101,6 +107,13 @@ struct Lane {
     struct FrameGraph {
         int az_begin = 0, az_end = 0, n_frames = 0; const void* cols = nullptr; unsigned short rows[kMaxPasses] = {};
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; hipGraphNode_t pose_node = nullptr; uint64_t last_use = 0; int hits = 0;
+        // Replays must not touch a launch that is still queued or running: whether hipGraphExecKernelNodeSetParams rewrites the
+        // kernel arguments of an exec IN PLACE is the runtime's business (advisor, round 5: lane reuse is ordered on the device
+        // only, the host never waits), so the library does not depend on it -- TWO execs per shape, used alternately, each with
+        // an event behind its last launch; the host waits for that event before it re-sets the exec's poses or destroys it.
+        // The exec about to be updated was launched two uses of this shape ago: the wait is over before it starts, except for a
+        // caller that runs more than a whole lane rotation ahead of the GPU
+        hipGraphExec_t ge2 = nullptr; hipEvent_t ev[2] = { nullptr, nullptr }; bool ev_pending[2] = { false, false }; int flip = 0;
         hipKernelNodeParams pose_kp{};     // the pass-0 trace node as captured (grid, block, LDS) ...
         Params pose_P;                     // ... and the Params bytes it was captured with
     };
@@ -194,6 +207,13 @@ struct rr_ctx {
     int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
     int seg_chunk = 16;          // later-pass trace grids in chunks of S neighbouring segments, segment-fast inside a chunk (RR_TRACE_CHUNK; 0: rows of one segment)
     int cull_pop = 1;            // k_trace's later passes drop stack entries at pop time (RR_CULL_POP=0: off; the images are the same either way)
+    // a deferred host copy that cannot ride on a later-pass trace launch (one-pass frames, the last batch of a run, a caller
+    // with a single batch in flight) is stored by the library's own kernel (k_copy_host) when the destination is page-locked:
+    // flush_blocks one-wave workgroups with at most flush_inflight 1-KB stores outstanding each (RR_FLUSH_BLOCKS, RR_FLUSH_INFLIGHT;
+    // RR_FLUSH_KERNEL=0: hipMemcpyAsync, i.e. whichever engine the process' HIP runtime picks)
+    int flush_kernel = 1, flush_blocks = 32, flush_inflight = 4;
+    int flush_threads = 64, flush_nt = 0;     // threads per workgroup of the copy kernel (RR_FLUSH_THREADS), nontemporal stores (RR_FLUSH_NT)
+    int flush_xcd = 0;           // the copy kernel's workgroups all on this XCD (RR_FLUSH_XCD 0..7; -1: dealt out over all eight)
     int copy_blocks = 8;         // workgroups (one wave each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
     int tight_grid = 1;          // later-pass trace rows sized by what earlier batches needed (RR_TIGHT_GRID=0: the doubling bound)
     int tight_force = 0;         // RR_TIGHT_FORCE=n: rows of n workgroups whatever the history says (tests of the repair path)
@@ -427,9 +447,19 @@ int upload_tables(rr_ctx* c)
     return 0;
 }
 
+void drop_graph(Lane::FrameGraph& fg)
+{
+    for (int k = 0; k < 2; k++) {       // an exec is destroyed only after its last launch has left the GPU
+        if (fg.ev[k]) { if (fg.ev_pending[k]) (void)hipEventSynchronize(fg.ev[k]); (void)hipEventDestroy(fg.ev[k]); fg.ev[k] = nullptr; fg.ev_pending[k] = false; }
+    }
+    if (fg.ge) (void)hipGraphExecDestroy(fg.ge);
+    if (fg.ge2) (void)hipGraphExecDestroy(fg.ge2);
+    if (fg.g) (void)hipGraphDestroy(fg.g);
+    fg.ge = fg.ge2 = nullptr; fg.g = nullptr;
+}
 void drop_graphs(Lane& L)
 {
-    for (Lane::FrameGraph& fg : L.graphs) { if (fg.ge) (void)hipGraphExecDestroy(fg.ge); if (fg.g) (void)hipGraphDestroy(fg.g); }
+    for (Lane::FrameGraph& fg : L.graphs) drop_graph(fg);
     L.graphs.clear();
 }
 
@@ -552,6 +582,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.pass0_az = c->pass0_az;
     P.cull_pop = c->cull_pop; P.seg_chunk = c->seg_chunk;
     P.grid_hint = L.d_hint.p; P.ovf_list = L.d_ovf_list.p; P.ovf_stride = L.ovf_stride;     // rows stay at the bound until run_frame tightens them
+    P.hist_host = (c->tight_grid && g.n_reflections > 1) ? L.h_hist : nullptr;              // the chain's k_column stores the history there (read without a fence by later batches)
 }
 
 // a free copy record of the lane (waits for the oldest copy if both are still in flight)
@@ -564,13 +595,32 @@ int take_rec(rr_ctx* c, Lane& L, Lane::CopyRec** out)
     return 0;
 }
 
+// device -> host on stream s: the library's own copy kernel when the destination is page-locked (`visible`) and everything is
+// 16-byte aligned, else hipMemcpyAsync (rr_copy_to_host_async in the header says why)
+int copy_out(rr_ctx* c, const void* d_src, void* h_dst, size_t bytes, bool visible, hipStream_t s)
+{
+    if (bytes == 0) return 0;
+    if (c->flush_kernel && visible && bytes % 16 == 0 && ((uintptr_t)h_dst | (uintptr_t)d_src) % 16 == 0) {
+        launch_copy_host(d_src, h_dst, bytes, c->flush_blocks, c->flush_inflight, c->flush_xcd, s, c->flush_threads, c->flush_nt);
+        RR_HIP(c, hipGetLastError());
+    } else RR_HIP(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+bool host_visible(const void* p)
+{
+    hipPointerAttribute_t at;
+    const bool v = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();     // a pageable pointer makes hipPointerGetAttributes fail: not an error of the caller's call
+    return v;
+}
+
 // the lane's deferred host copy, now, as a plain copy on the stream its batch ran on
 int flush_deferred(rr_ctx* c, Lane& L)
 {
     if (!L.deferred) return 0;
     Lane::CopyRec* r = nullptr;
     int rc = take_rec(c, L, &r); if (rc) return rc;
-    RR_HIP(c, hipMemcpyAsync(L.def_dst, L.d_img_u8.p, L.def_bytes, hipMemcpyDeviceToHost, L.def_stream));
+    { const int rcc = copy_out(c, L.d_img_u8.p, L.def_dst, L.def_bytes, L.def_foldable, L.def_stream); if (rcc) return rcc; }
     RR_HIP(c, hipEventRecord(r->ev, L.def_stream));
     r->dst = L.def_dst; r->pending = true;
     RR_HIP(c, hipEventRecord(L.ev_consumed, L.def_stream));
@@ -589,6 +639,20 @@ struct TimedScope {
     }
     ~TimedScope() {
         if (on) { (void)hipEventRecord(b, s); c->timers[name].pending.emplace_back(a, b); }
+        if (c->roctx) roctx_pop();
+    }
+};
+
+// timing mode 1, kernels of the frame chain: the launch's own begin / end timestamps (hipExtLaunchKernel events) -- a kernel's
+// duration as rocprofv3 reports it, whatever it waited for before it started (TimedScope's stream events include that wait)
+struct KernelEvents {
+    rr_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    KernelEvents(rr_ctx* c_, const char* n_) : c(c_), name(n_) {
+        if (c->timing == 1) { a = c->take_event(); b = c->take_event(); }
+        if (c->roctx) roctx_push(name);
+    }
+    ~KernelEvents() {
+        if (a) c->timers[name].pending.emplace_back(a, b);
         if (c->roctx) roctx_pop();
     }
 };
@@ -704,18 +768,22 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         if (c->timing) {
             // the kernel's own begin/end timestamps (hipExtLaunchKernel events), on its launch stream
             hipEvent_t a = c->take_event(), b = c->take_event();
-            launch_trace(Q, pass, &pa, c->stats_mode, s, a, b);
+            // ... and of the repair launch behind a tightened row (timer "trace_repair": the trace figure does not contain it)
+            const bool rep = pass > 0 && pass < kMaxPasses && Q.tight_groups[pass];
+            hipEvent_t ra = rep ? c->take_event() : nullptr, rb = rep ? c->take_event() : nullptr;
+            bool launched = false;
+            launch_trace(Q, pass, &pa, c->stats_mode, s, a, b, ra, rb, &launched);
             c->timers[pass == 0 ? "trace0" : "trace"].pending.emplace_back(a, b);
+            if (launched) c->timers["trace_repair"].pending.emplace_back(ra, rb);
+            else if (rep) { c->event_pool.push_back(ra); c->event_pool.push_back(rb); }
         } else {
             launch_trace(Q, pass, &pa, c->stats_mode, s);
         }
         if (c->roctx) roctx_pop();
-        { TimedScope t(c, s, "shade"); launch_shade(Q, pass, s); }
-        if (pass < g.n_reflections - 1) { TimedScope t(c, s, "scan"); launch_scan(Q, pass, s); }
+        { KernelEvents t(c, "shade"); launch_shade(Q, pass, s, t.a, t.b); }
+        if (pass < g.n_reflections - 1) { KernelEvents t(c, "scan"); launch_scan(Q, pass, s, t.a, t.b); }
     }
-    { TimedScope t(c, s, "column"); launch_column(Q, s); }
-    // the history this batch leaves behind travels to the host behind it (96 B; read without a fence by later batches)
-    if (c->tight_grid && g.n_reflections > 1) RR_HIP(c, hipMemcpyAsync(L.h_hist, L.d_hint.p->hist, kMaxPasses * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    { KernelEvents t(c, "column"); launch_column(Q, s, t.a, t.b); }
     return 0;
     };
     // Launch graphs: a chain that has been issued before with the same shape is captured once and replayed -- one
@@ -734,8 +802,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
             if (L.graphs.size() >= 12) {           // forget the least recently used shape
                 size_t lru = 0;
                 for (size_t k = 1; k < L.graphs.size(); k++) if (L.graphs[k].last_use < L.graphs[lru].last_use) lru = k;
-                if (L.graphs[lru].ge) (void)hipGraphExecDestroy(L.graphs[lru].ge);
-                if (L.graphs[lru].g) (void)hipGraphDestroy(L.graphs[lru].g);
+                drop_graph(L.graphs[lru]);
                 L.graphs.erase(L.graphs.begin() + (long)lru);
             }
             Lane::FrameGraph n;
@@ -753,8 +820,9 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
                 hipGraph_t gph = nullptr;
                 e = hipStreamEndCapture(s, &gph);
                 if (rcq == 0 && e == hipSuccess && gph) {
-                    hipGraphExec_t ge = nullptr;
-                    if (hipGraphInstantiate(&ge, gph, nullptr, nullptr, 0) == hipSuccess) {
+                    hipGraphExec_t ge = nullptr, ge2 = nullptr;
+                    if (hipGraphInstantiate(&ge, gph, nullptr, nullptr, 0) == hipSuccess && hipGraphInstantiate(&ge2, gph, nullptr, nullptr, 0) == hipSuccess &&
+                        hipEventCreateWithFlags(&fg->ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&fg->ev[1], hipEventDisableTiming) == hipSuccess) {
                         size_t nn = 0; (void)hipGraphGetNodes(gph, nullptr, &nn);
                         std::vector<hipGraphNode_t> nodes(nn); (void)hipGraphGetNodes(gph, nodes.data(), &nn);
                         for (hipGraphNode_t nd : nodes) {
@@ -764,9 +832,10 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
                                 fg->pose_node = nd; fg->pose_kp = kp; fg->pose_P = trace0_params(P); break;
                             }
                         }
-                        if (fg->pose_node) { fg->g = gph; fg->ge = ge; c->graph_captures++; }
-                        else { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gph); }
-                    } else (void)hipGraphDestroy(gph);
+                        if (fg->pose_node) { fg->g = gph; fg->ge = ge; fg->ge2 = ge2; c->graph_captures++; }
+                        else { (void)hipGraphExecDestroy(ge); (void)hipGraphExecDestroy(ge2); (void)hipGraphDestroy(gph); }
+                    } else { if (ge) (void)hipGraphExecDestroy(ge); if (ge2) (void)hipGraphExecDestroy(ge2); (void)hipGraphDestroy(gph); }
+                    if (!fg->ge) for (int k = 0; k < 2; k++) if (fg->ev[k]) { (void)hipEventDestroy(fg->ev[k]); fg->ev[k] = nullptr; }
                 } else if (gph) (void)hipGraphDestroy(gph);
             }
             (void)hipGetLastError();
@@ -777,9 +846,13 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
             void* args[3] = { (void*)&fg->pose_P, (void*)&pass0, (void*)&pa };
             hipKernelNodeParams kp = fg->pose_kp;
             kp.kernelParams = args; kp.extra = nullptr;
-            hipError_t e;
-            { HostProfScope hp(3, "ctx:   graph: set the poses"); e = hipGraphExecKernelNodeSetParams(fg->ge, fg->pose_node, &kp); }
-            { HostProfScope hp(4, "ctx:   graph: launch"); if (e == hipSuccess) e = hipGraphLaunch(fg->ge, s); }
+            hipError_t e = hipSuccess;
+            const int w = fg->flip; fg->flip ^= 1;
+            hipGraphExec_t ex = w ? fg->ge2 : fg->ge;
+            if (fg->ev_pending[w]) { HostProfScope hp(6, "ctx:   graph: wait for the exec's previous launch"); e = hipEventSynchronize(fg->ev[w]); fg->ev_pending[w] = false; }
+            { HostProfScope hp(3, "ctx:   graph: set the poses"); if (e == hipSuccess) e = hipGraphExecKernelNodeSetParams(ex, fg->pose_node, &kp); }
+            { HostProfScope hp(4, "ctx:   graph: launch"); if (e == hipSuccess) e = hipGraphLaunch(ex, s); }
+            if (e == hipSuccess) { e = hipEventRecord(fg->ev[w], s); fg->ev_pending[w] = e == hipSuccess; }
             if (e != hipSuccess) return fail(c, -100, std::string("launch graph replay: ") + hipGetErrorString(e));
             c->graph_replays++;
             return 0;
@@ -861,6 +934,12 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_TRACE_CHUNK")) c->seg_chunk = std::max(0, std::min(1024, atoi(getenv("RR_TRACE_CHUNK"))));
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
     if (getenv("RR_GRAPHS")) c->use_graphs = atoi(getenv("RR_GRAPHS")) != 0;
+    if (getenv("RR_FLUSH_KERNEL")) c->flush_kernel = atoi(getenv("RR_FLUSH_KERNEL")) != 0;
+    if (getenv("RR_FLUSH_BLOCKS")) c->flush_blocks = std::max(1, std::min(1024, atoi(getenv("RR_FLUSH_BLOCKS"))));
+    if (getenv("RR_FLUSH_INFLIGHT")) c->flush_inflight = std::max(0, std::min(64, atoi(getenv("RR_FLUSH_INFLIGHT"))));
+    if (getenv("RR_FLUSH_XCD")) c->flush_xcd = std::max(-1, std::min(7, atoi(getenv("RR_FLUSH_XCD"))));
+    if (getenv("RR_FLUSH_THREADS")) c->flush_threads = std::max(64, std::min(1024, atoi(getenv("RR_FLUSH_THREADS"))));
+    if (getenv("RR_FLUSH_NT")) c->flush_nt = atoi(getenv("RR_FLUSH_NT")) != 0;
     if (getenv("RR_TIGHT_GRID")) c->tight_grid = atoi(getenv("RR_TIGHT_GRID")) != 0;
     if (getenv("RR_TIGHT_FORCE")) c->tight_force = std::max(0, atoi(getenv("RR_TIGHT_FORCE")));
     {   // the one angle of total reflection that does not depend on the material table
@@ -1257,18 +1336,14 @@ int rr_simulate_batch_columns_carry_device(rr_ctx* c, const float* poses, int n_
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));
     // the carried copy rides on the later-pass trace launches (a few waves, one 1-KB store per wave in flight: Params::copy_src)
     // when there are such launches and the destination is page-locked; else it is a plain copy ahead of the batch
-    bool fold = carry_bytes > 0 && c->copy_blocks > 0 && eff_config(c).n_reflections >= 2 && carry_bytes % 16 == 0 && !c->stats_mode &&
-                ((uintptr_t)d_carry_src | (uintptr_t)h_carry_dst) % 16 == 0;
-    if (fold) {
-        hipPointerAttribute_t at;
-        fold = hipPointerGetAttributes(&at, h_carry_dst) == hipSuccess && at.type == hipMemoryTypeHost;
-        (void)hipGetLastError();
-    }
-    if (carry_bytes && !fold) RR_HIP(c, hipMemcpyAsync(h_carry_dst, d_carry_src, carry_bytes, hipMemcpyDeviceToHost, s));
+    const bool visible = carry_bytes > 0 && host_visible(h_carry_dst);
+    const bool fold = visible && c->copy_blocks > 0 && eff_config(c).n_reflections >= 2 && carry_bytes % 16 == 0 && !c->stats_mode &&
+                      ((uintptr_t)d_carry_src | (uintptr_t)h_carry_dst) % 16 == 0;
+    if (carry_bytes && !fold) { const int rcc = copy_out(c, d_carry_src, h_carry_dst, carry_bytes, visible, s); if (rcc) return rcc; }
     rc = run_frame(c, L, poses, az_begin, az_end, d_cols_u8, nullptr, s, n_frames, nullptr, 0, false,
                    fold ? (const uint8_t*)d_carry_src : nullptr, fold ? (uint8_t*)h_carry_dst : nullptr, fold ? carry_bytes : 0);
     if (rc) {
-        if (fold) RR_HIP(c, hipMemcpyAsync(h_carry_dst, d_carry_src, carry_bytes, hipMemcpyDeviceToHost, s));    // refused before any launch: the copy still happens
+        if (fold) (void)copy_out(c, d_carry_src, h_carry_dst, carry_bytes, true, s);    // refused before any launch: the copy still happens
         return rc;
     }
     RR_HIP(c, hipEventRecord(L.ev_consumed, s));
@@ -1309,6 +1384,14 @@ void* rr_host_alloc(size_t bytes)
 
 void rr_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+int rr_copy_to_host_async(rr_ctx* c, const void* d_src, void* h_dst, size_t bytes, void* stream)
+{
+    if (!c) return -1;
+    if (bytes && (!d_src || !h_dst)) return fail(c, -3, "rr_copy_to_host_async: null pointer");
+    RR_HIP(c, hipSetDevice(c->device));
+    return copy_out(c, d_src, h_dst, bytes, bytes > 0 && host_visible(h_dst), stream ? (hipStream_t)stream : c->stream);
+}
+
 int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, uint8_t* h_imgs_u8, void* stream)
 {
     int rc = check_ready(c); if (rc) return rc;
@@ -1346,7 +1429,7 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames, nullptr, 0, false, job_src, job_dst, job_bytes);
     if (rc) {
         if (fold) {     // the frame was refused before any launch: the folded copy still has to happen
-            RR_HIP(c, hipMemcpyAsync(job_dst, job_src, job_bytes, hipMemcpyDeviceToHost, s));
+            (void)copy_out(c, job_src, job_dst, job_bytes, true, s);
             RR_HIP(c, hipEventRecord(rec->ev, s)); rec->dst = job_dst; rec->pending = true;
         }
         return rc;
@@ -1368,9 +1451,7 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     // they fill its write queues the stores of every other kernel wait behind them.  So the copy is DEFERRED to the lane's
     // next batch and trickled out by a few waves of its later-pass trace launches with ONE store per wave in flight
     // (k_trace, Params::copy_src): 3,980-4,025 images/s, within 1 % of the HBM-resident rate.
-    hipPointerAttribute_t at;
-    const bool device_visible = hipPointerGetAttributes(&at, h_imgs_u8) == hipSuccess && at.type == hipMemoryTypeHost;
-    (void)hipGetLastError();     // a pageable pointer makes hipPointerGetAttributes fail: not an error of this call
+    const bool device_visible = host_visible(h_imgs_u8);
     L.deferred = true; L.def_dst = h_imgs_u8; L.def_bytes = bytes; L.def_stream = s; L.def_foldable = device_visible;
     return 0;
 }
@@ -1712,7 +1793,9 @@ int rr_peek_error_bits_async(rr_ctx* c, uint32_t* h_bits, void* stream)
     RR_HIP(c, hipSetDevice(c->device));
     Lane& L = c->lanes[c->last_lane];
     if (!L.d_sticky.p) { *h_bits = 0; return 0; }     // no frame has run on this lane yet
-    RR_HIP(c, hipMemcpyAsync(h_bits, L.d_sticky.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream ? (hipStream_t)stream : c->stream));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (c->flush_kernel && host_visible(h_bits)) { launch_store_u32(L.d_sticky.p, h_bits, s); RR_HIP(c, hipGetLastError()); }     // (a kernel's store: no copy engine involved)
+    else RR_HIP(c, hipMemcpyAsync(h_bits, L.d_sticky.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return 0;
 }
 
@@ -1792,9 +1875,9 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
         RR_HIP(c, hipMemcpyAsync(h8.data(), L.d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
         if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), L.d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
-    RR_HIP(c, hipMemcpyAsync(h_cnt, L.d_counters.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-    if (stats && L.d_seg_stats.p && g.n_reflections > 0)
-        RR_HIP(c, hipMemcpyAsync(h_ss, L.d_seg_stats.p, n_st * sizeof(SegStats), hipMemcpyDeviceToHost, c->stream));
+    // error bits / counters and the per-pass statistics: one kernel's stores into the page-locked block
+    launch_frame_report(L.d_counters.p, L.d_seg_stats.p, (stats && L.d_seg_stats.p && g.n_reflections > 0) ? n_st : 0, c->h_frame, c->stream);
+    RR_HIP(c, hipGetLastError());
     RR_HIP(c, hipEventRecord(L.ev_consumed, c->stream));
     L.pending_consume = true;
     RR_HIP(c, hipStreamSynchronize(c->stream));
@@ -1911,6 +1994,43 @@ int rr_get_bvh_info(rr_ctx* c, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* de
     if (n_tris) *n_tris = c->n_tris;
     if (depth) *depth = c->depth;
     if (stack_need) *stack_need = c->stack_need;
+    return 0;
+}
+
+int rr_debug_fresnel(rr_ctx* c, size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
+                     float* out_refl_dir, double* out_refl_energy, float* out_refr_dir, double* out_refr_energy)
+{
+    if (!c) return -1;
+    if (n == 0) return 0;
+    if (!normals || !dirs || !energy || !v1 || !v2 || !out_refl_dir || !out_refl_energy || !out_refr_dir || !out_refr_energy)
+        return fail(c, -3, "rr_debug_fresnel: null pointer");
+    RR_HIP(c, hipSetDevice(c->device));
+    DevBuf<float> d_n, d_d, d_v2, d_rd, d_td; DevBuf<double> d_e, d_v1, d_re, d_te;
+    hipError_t e = d_n.ensure(3 * n);
+    if (e == hipSuccess) e = d_d.ensure(3 * n);
+    if (e == hipSuccess) e = d_v2.ensure(n);
+    if (e == hipSuccess) e = d_rd.ensure(3 * n);
+    if (e == hipSuccess) e = d_td.ensure(3 * n);
+    if (e == hipSuccess) e = d_e.ensure(n);
+    if (e == hipSuccess) e = d_v1.ensure(n);
+    if (e == hipSuccess) e = d_re.ensure(n);
+    if (e == hipSuccess) e = d_te.ensure(n);
+    if (e == hipSuccess) e = hipMemcpy(d_n.p, normals, 3 * n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d.p, dirs, 3 * n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_v2.p, v2, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_e.p, energy, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_v1.p, v1, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_debug_fresnel(n, d_n.p, d_d.p, d_e.p, d_v1.p, d_v2.p, d_rd.p, d_re.p, d_td.p, d_te.p, c->stream);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_refl_dir, d_rd.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_refr_dir, d_td.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_refl_energy, d_re.p, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_refr_energy, d_te.p, n * sizeof(double), hipMemcpyDeviceToHost);
+    d_n.release(); d_d.release(); d_v2.release(); d_rd.release(); d_td.release(); d_e.release(); d_v1.release(); d_re.release(); d_te.release();
+    if (e != hipSuccess) return fail(c, -100, std::string("rr_debug_fresnel: ") + hipGetErrorString(e));
     return 0;
 }
 

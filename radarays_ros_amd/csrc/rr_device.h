@@ -80,6 +80,7 @@ struct Counters {
     unsigned int max_iters, n_waves;  // longest wave, wave count
     unsigned int overflow, pad;       // error bits, set on rare error paths
     unsigned long long it_all, it_node, it_leaf, quad_steps;   // stats mode: wave-loop iterations (all / issuing the node path / the leaf path), quad steps
+    unsigned long long pad2;          // (a multiple of 16 bytes: k_frame_report moves it as uint4)
 };
 
 // Tight later-pass trace grids (round 5).  A segment holds at most n_beam * 2^pass waves in pass `pass`, and launch_trace
@@ -180,6 +181,7 @@ struct Params {
     int cull_pop;            // later passes / rr_debug_trace: drop stack entries at pop time by their 16-bit distance bound (0: off, RR_CULL_POP=0)
     // tight later-pass trace grids (GridHint above)
     GridHint* grid_hint;     // per lane; null: off
+    uint32_t* hist_host;     // page-locked host copy of grid_hint->hist (kMaxPasses words), written by the chain's k_column: the host reads it as a hint, without a fence.  A store from a kernel, not a 96-byte hipMemcpyAsync: which engine carries such a copy is the runtime's choice (the one bundled with the torch wheel runs a blit kernel per copy, 481 of them in a profiled run of the target)
     uint32_t* ovf_list;      // [n_passes][ovf_stride] segments whose count exceeds the tightened row of that pass
     int ovf_stride;
     unsigned short tight_groups[kMaxPasses];   // 16-ray workgroups per segment row of pass p; 0: the full doubling bound

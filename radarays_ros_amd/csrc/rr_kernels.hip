@@ -551,6 +551,28 @@ __device__ inline void fresnel_split(V3 n, const V3 d, const float incidence_f, 
     tenergy = Teff * energy;
 }
 
+// test hook (rr_debug_fresnel): fresnel_split exactly as k_shade calls it -- the incidence angle by acosf of the f32 dot product
+// (one value for Fresnel and BRDF), the angle of total reflection by the function that fills the material table
+__global__ void k_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
+                                float* out_rdir, double* out_re, float* out_tdir, double* out_te)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 nrm = { normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] }, d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
+    const float inc = acosf_ref(v_dot(v_neg(d), nrm));
+    const double v2d = (double)v2[i];
+    V3 rdir, tdir; double re, te;
+    fresnel_split(nrm, d, inc, energy[i], v1[i], v2d, fresnel_angle_limit(v1[i], v2d), rdir, re, tdir, te);
+    out_rdir[3 * i] = rdir.x; out_rdir[3 * i + 1] = rdir.y; out_rdir[3 * i + 2] = rdir.z;
+    out_tdir[3 * i] = tdir.x; out_tdir[3 * i + 1] = tdir.y; out_tdir[3 * i + 2] = tdir.z;
+    out_re[i] = re; out_te[i] = te;
+}
+void launch_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
+                          float* out_rdir, double* out_re, float* out_tdir, double* out_te, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_debug_fresnel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, normals, dirs, energy, v1, v2, out_rdir, out_re, out_tdir, out_te);
+}
+
 // NOT in the reference checkout (its Cook-Torrance model lives on the dev/flex branch, README.md:83-85):
 // this build's own specification for BASELINE.json configs[4], PARITY UNPINNED.  The cos^C lobe of the
 // shader below is replaced by the microfacet backscatter lobe D_GGX * G_Smith, normalised to 1 at normal
@@ -1250,6 +1272,9 @@ __global__ __launch_bounds__(kColThreads) void k_column(const Params P)
         P.cols_u8[(size_t)seg * n_cells + i] = saturate_u8(v);   // :542
         if (P.cols_f32) P.cols_f32[(size_t)seg * n_cells + i] = v;
     }
+    // the history of per-pass wave counts this batch leaves behind (GridHint, written by the k_scan launches before this
+    // one) goes to the host's page-locked copy: 96 bytes, one workgroup
+    if (blockIdx.x == 0 && P.hist_host && P.grid_hint && tid < kMaxPasses) P.hist_host[tid] = P.grid_hint->hist[tid];
 }
 
 // ---------------------------------------------------------------------------
@@ -1370,6 +1395,73 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t* __restrict__ imgs,
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&sse[blockIdx.y], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
+// ---------------------------------------------------------------------------
+// Host delivery without the runtime's copy engines: device memory -> page-locked host memory, stored by a kernel.
+// Which engine a hipMemcpyAsync to page-locked memory runs on is the HIP runtime's choice -- the runtime bundled with the
+// torch wheel (ROCm 7.0.2) launches a blit kernel (`__amd_rocclr_copyBuffer`) that competes with the frame kernels and reads
+// 27-36k images/s on config 2, the image's own runtime uses SDMA (39.4k = the link) -- so a caller's process decided how fast
+// the library delivers.  This kernel is the library's own: one-wave workgroups, 16 B per lane (1 KB per wave and store),
+// at most `inflight` stores per wave outstanding (0: no limit).  The limit is what keeps the stores of OTHER kernels from
+// queueing behind PCIe-paced writes in the memory pipeline (the 7 % of DESIGN.md §5); a flush at the end of a run, with
+// nothing else on the chip, takes none.
+// XCD confinement (xcd >= 0): the hardware deals the workgroups of a launch out to the 8 XCDs round robin in flat order, and
+// each XCD has its own L2 and its own path into the fabric; PCIe-paced stores fill the write queues of the XCD they come
+// from, and every other kernel's stores on THAT XCD wait behind them.  A launch of 8 x blocks workgroups of which only those
+// with blockIdx % 8 == xcd work keeps the damage to one eighth of the chip.
+// grid `blocks` (8 x blocks when confined), block 64
+// ---------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(1024) void k_copy_host(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int inflight, int xcd)
+{
+    unsigned b = blockIdx.x, nb = gridDim.x;
+    if (xcd >= 0) {
+        if ((int)(b & 7u) != xcd) return;
+        b >>= 3; nb >>= 3;
+    }
+    const size_t nthreads = (size_t)nb * blockDim.x;
+    int k = 0;
+    for (size_t i = (size_t)b * blockDim.x + threadIdx.x; i < n16; i += nthreads) {
+        const uint4 v = src[i];
+        if (NT) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w = { v.x, v.y, v.z, v.w };
+            __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst) + i);
+        } else dst[i] = v;
+        if (inflight > 0 && ++k >= inflight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k = 0; }
+    }
+}
+void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int nt)
+{
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return;
+    threads = std::max(64, std::min(1024, threads)) & ~63;
+    unsigned g = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)blocks, (n16 + threads - 1) / threads));
+    if (xcd >= 0) g *= 8u;
+    if (nt) hipLaunchKernelGGL(k_copy_host<true>, dim3(g), dim3(threads), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, inflight, xcd);
+    else hipLaunchKernelGGL(k_copy_host<false>, dim3(g), dim3(threads), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, inflight, xcd);
+}
+
+// what rr_simulate reports beside the image -- the frame's error bits / counters and its per-pass segment statistics -- into
+// ONE page-locked block (Counters, then n_ss SegStats): a kernel's stores instead of two small hipMemcpyAsync
+__global__ __launch_bounds__(256) void k_frame_report(const Counters* __restrict__ cnt, const SegStats* __restrict__ ss, size_t n_ss, void* h_dst)
+{
+    static_assert(sizeof(Counters) % 16 == 0 && sizeof(SegStats) == 16, "report layout");
+    const uint4* a = reinterpret_cast<const uint4*>(cnt);
+    uint4* d = reinterpret_cast<uint4*>(h_dst);
+    constexpr size_t nc = sizeof(Counters) / 16;
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < nc; i += stride) d[i] = a[i];
+    const uint4* b = reinterpret_cast<const uint4*>(ss);
+    for (size_t i = i0; i < n_ss; i += stride) d[nc + i] = b[i];
+}
+__global__ void k_store_u32(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) { *dst = *src; }
+void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, src, h_dst); }
+void launch_frame_report(const Counters* cnt, const SegStats* ss, size_t n_ss, void* h_dst, hipStream_t s)
+{
+    const unsigned g = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (n_ss + 255) / 256));
+    hipLaunchKernelGGL(k_frame_report, dim3(g), dim3(256), 0, s, cnt, ss, n_ss, h_dst);
+}
+
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(64, (npx / 16 + 255) / 256));
@@ -1409,8 +1501,10 @@ void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStr
                                    reinterpret_cast<TriRec*>(reinterpret_cast<float4*>(nodes) + tri_base4), n_tris);
 }
 
-void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
+                  hipEvent_t ev_rep_start, hipEvent_t ev_rep_stop, bool* repair_launched)
 {
+    if (repair_launched) *repair_launched = false;
     const int n_seg = (pass == 0 && P.set_mode) ? P.n_groups * P.n_loc : P.n_seg;
     // pass 0: one flat sequence of n_seg x n_beam rays; later passes: a row of blocks per segment
     const int A0 = P.pass0_az, Sw0 = kRaysPerWave / A0;
@@ -1461,8 +1555,13 @@ void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, 
 #undef RR_LAUNCH_TRACE0
     if (pass > 0 && pass < kMaxPasses && P.tight_groups[pass]) {     // host guarantees: no statistics build, no spill path
         const dim3 rgrid(128);
-        if (cull) hipLaunchKernelGGL((k_trace_repair<true>), rgrid, block, lds, s, Pl, pass);
-        else      hipLaunchKernelGGL((k_trace_repair<false>), rgrid, block, lds, s, Pl, pass);
+        // (its own pair of events in timing mode: the repair is not inside the trace launch's begin / end)
+        if (!ev_rep_start) {
+            if (cull) hipLaunchKernelGGL((k_trace_repair<true>), rgrid, block, lds, s, Pl, pass);
+            else      hipLaunchKernelGGL((k_trace_repair<false>), rgrid, block, lds, s, Pl, pass);
+        } else if (cull) hipExtLaunchKernelGGL((k_trace_repair<true>), rgrid, block, lds, s, ev_rep_start, ev_rep_stop, 0, Pl, pass);
+        else             hipExtLaunchKernelGGL((k_trace_repair<false>), rgrid, block, lds, s, ev_rep_start, ev_rep_stop, 0, Pl, pass);
+        if (repair_launched) *repair_launched = true;
     }
 }
 
@@ -1472,27 +1571,38 @@ void* trace0_kernel(bool spill) { return spill ? (void*)k_trace<true, false, tru
 // ... and the Params bytes launch_trace hands that kernel
 Params trace0_params(const Params& P) { Params Pl = P; Pl.copy_blocks = 0; return Pl; }
 
-void launch_shade(const Params& P, int pass, hipStream_t s)
+// (ev_start / ev_stop, timing mode: the dispatch's own begin / end timestamps -- what rocprofv3 reports as the kernel's
+// duration -- not the time the launch spent waiting for the kernels of other streams)
+void launch_shade(const Params& P, int pass, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int cap_p = (int)std::min<long>((long)P.cap, pass < 20 ? (long)P.n_beam << pass : (long)P.cap);   // see launch_trace
     dim3 grid((cap_p + 63) / 64, P.n_seg), block(64);
-    if (pass == 0) hipLaunchKernelGGL((k_shade<true>), grid, block, 0, s, P, pass);
-    else           hipLaunchKernelGGL((k_shade<false>), grid, block, 0, s, P, pass);
+    if (!ev_start) {
+        if (pass == 0) hipLaunchKernelGGL((k_shade<true>), grid, block, 0, s, P, pass);
+        else           hipLaunchKernelGGL((k_shade<false>), grid, block, 0, s, P, pass);
+    } else if (pass == 0) hipExtLaunchKernelGGL((k_shade<true>), grid, block, 0, s, ev_start, ev_stop, 0, P, pass);
+    else                  hipExtLaunchKernelGGL((k_shade<false>), grid, block, 0, s, ev_start, ev_stop, 0, P, pass);
 }
 
-void launch_scan(const Params& P, int pass, hipStream_t s)
+void launch_scan(const Params& P, int pass, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     dim3 grid(P.n_seg), block(256);
-    if (pass == 0) hipLaunchKernelGGL((k_scan<true>), grid, block, 0, s, P, pass);
-    else           hipLaunchKernelGGL((k_scan<false>), grid, block, 0, s, P, pass);
+    if (!ev_start) {
+        if (pass == 0) hipLaunchKernelGGL((k_scan<true>), grid, block, 0, s, P, pass);
+        else           hipLaunchKernelGGL((k_scan<false>), grid, block, 0, s, P, pass);
+    } else if (pass == 0) hipExtLaunchKernelGGL((k_scan<true>), grid, block, 0, s, ev_start, ev_stop, 0, P, pass);
+    else                  hipExtLaunchKernelGGL((k_scan<false>), grid, block, 0, s, ev_start, ev_stop, 0, P, pass);
 }
 
-void launch_column(const Params& P, hipStream_t s)
+void launch_column(const Params& P, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     dim3 grid(P.n_seg);
     const size_t lds = (((size_t)P.n_cells * sizeof(float)) + 15) & ~(size_t)15;
-    if (P.n_seg >= 1024) hipLaunchKernelGGL(k_column<256>, grid, dim3(256), lds, s, P);
-    else hipLaunchKernelGGL(k_column<512>, grid, dim3(512), lds, s, P);
+    if (!ev_start) {
+        if (P.n_seg >= 1024) hipLaunchKernelGGL(k_column<256>, grid, dim3(256), lds, s, P);
+        else hipLaunchKernelGGL(k_column<512>, grid, dim3(512), lds, s, P);
+    } else if (P.n_seg >= 1024) hipExtLaunchKernelGGL(k_column<256>, grid, dim3(256), lds, s, ev_start, ev_stop, 0, P);
+    else hipExtLaunchKernelGGL(k_column<512>, grid, dim3(512), lds, s, ev_start, ev_stop, 0, P);
 }
 
 void launch_assemble_u8(const uint8_t* cols, uint8_t* img, int n_angles, int n_cells, int scroll, hipStream_t s,

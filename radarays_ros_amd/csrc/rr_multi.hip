@@ -49,6 +49,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    int version = 0;                       // ncclGetVersion's code (2.27.7 -> 22707), 0: the library does not say
     bool load(std::string& err) {
         if (lib) return true;
         for (const char* n : { "librccl.so.1", "librccl.so" }) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
@@ -56,6 +58,19 @@ struct Rccl {
 #define RR_SYM(f) f = (decltype(f))dlsym(lib, "nccl" #f); if (!f) { err = "rr_create_multi: librccl lacks nccl" #f; return false; }
         RR_SYM(CommInitAll) RR_SYM(CommDestroy) RR_SYM(Send) RR_SYM(Recv) RR_SYM(GroupStart) RR_SYM(GroupEnd) RR_SYM(GetErrorString)
 #undef RR_SYM
+        // The prototypes above are declared BY HAND (the library is loaded at run time, rccl.h is not included): they are those of
+        // the NCCL 2 API from 2.7 on (ncclSend / ncclRecv; rccl.h of ROCm 7.2: 2.27.7, checked against the header by
+        // tests/test_abi.py).  A library that reports a version outside [2.7, 3.0) is refused instead of being called
+        // through signatures nobody has compared; one that reports none is accepted and left to the self-test below
+        GetVersion = (decltype(GetVersion))dlsym(lib, "ncclGetVersion");
+        if (GetVersion && GetVersion(&version) == 0) {
+            const bool ok = (version >= 20900 && version < 30000) || (version >= 2700 && version < 2900);    // (2.9 changed the code's format)
+            if (!ok) {
+                err = "rr_create_multi: librccl reports NCCL version code " + std::to_string(version) +
+                      ", outside the range this library's hand-declared prototypes were checked for (2.7 .. 2.x)";
+                return false;
+            }
+        } else version = 0;
         return true;
     }
 };
@@ -153,6 +168,56 @@ int mfail(rr_multi* m, int code, const std::string& msg) { if (m) m->err = msg; 
 
 extern "C" {
 
+namespace {
+// Before the first real collective: does the hand-declared ABI mean what this file thinks it means?  Rank 0 of the
+// communicator sends 16 bytes of a 64-byte pattern to ITSELF (a send / recv pair to one's own rank inside a group is legal
+// NCCL) with the datatype constant this file calls ncclUint8 -- if that constant named a wider type, more than 16 bytes
+// would move and the guard bytes behind them would change; if the call signatures were off, nothing sensible would arrive.
+// With several devices every other rank then exchanges the same 16 bytes with rank 0, so the first gather of a frame is
+// not the first time two devices talk.
+bool rccl_selftest(rr_multi* m, std::string& why)
+{
+    const int n = (int)m->devices.size();
+    unsigned char pat[64], back[64];
+    for (int i = 0; i < 64; i++) pat[i] = (unsigned char)(0xA5 ^ (i * 7));
+    std::vector<unsigned char*> src((size_t)n, nullptr), dst((size_t)n, nullptr);
+    auto cleanup = [&]() { for (int i = 0; i < n; i++) { (void)hipSetDevice(m->devices[(size_t)i]); if (src[(size_t)i]) (void)hipFree(src[(size_t)i]); if (dst[(size_t)i]) (void)hipFree(dst[(size_t)i]); } (void)hipSetDevice(m->devices[0]); };
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; i++) {
+        e = hipSetDevice(m->devices[(size_t)i]);
+        if (e == hipSuccess) e = hipMalloc((void**)&src[(size_t)i], 64);
+        if (e == hipSuccess) e = hipMalloc((void**)&dst[(size_t)i], 64 * (size_t)(i == 0 ? n : 1));
+        if (e == hipSuccess) e = hipMemcpy(src[(size_t)i], pat, 64, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(dst[(size_t)i], 0, 64 * (size_t)(i == 0 ? n : 1));
+    }
+    if (e != hipSuccess) { why = std::string("buffers: ") + hipGetErrorString(e); cleanup(); return false; }
+    MultiSlot& S = m->slots[0];
+    ncclResult_t gr = g_rccl.GroupStart(), r1 = 0;
+    for (int i = 0; i < n && gr == 0 && r1 == 0 && e == hipSuccess; i++) {       // rank i -> rank 0 (i = 0: to itself), 16 of its 64 bytes
+        e = hipSetDevice(m->devices[(size_t)i]);
+        if (e == hipSuccess) r1 = g_rccl.Send(src[(size_t)i], 16, kNcclUint8, 0, m->comms[(size_t)i], S.streams[(size_t)i]);
+        if (e == hipSuccess && r1 == 0) e = hipSetDevice(m->devices[0]);
+        if (e == hipSuccess && r1 == 0) r1 = g_rccl.Recv(dst[0] + 64 * (size_t)i, 16, kNcclUint8, i, m->comms[0], S.streams[0]);
+    }
+    const ncclResult_t ger = g_rccl.GroupEnd();
+    if (e != hipSuccess || gr != 0 || r1 != 0 || ger != 0) {
+        why = e != hipSuccess ? std::string("hipSetDevice: ") + hipGetErrorString(e) : std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(gr ? gr : (r1 ? r1 : ger));
+        cleanup(); return false;
+    }
+    for (int i = 0; i < n && e == hipSuccess; i++) { e = hipSetDevice(m->devices[(size_t)i]); if (e == hipSuccess) e = hipStreamSynchronize(S.streams[(size_t)i]); }
+    bool ok = e == hipSuccess;
+    if (!ok) why = std::string("synchronize: ") + hipGetErrorString(e);
+    (void)hipSetDevice(m->devices[0]);
+    for (int i = 0; i < n && ok; i++) {
+        if (hipMemcpy(back, dst[0] + 64 * (size_t)i, 64, hipMemcpyDeviceToHost) != hipSuccess) { why = "read-back failed"; ok = false; break; }
+        if (std::memcmp(back, pat, 16) != 0) { why = "the 16 bytes rank " + std::to_string(i) + " sent did not arrive"; ok = false; }
+        for (int k = 16; k < 64 && ok; k++) if (back[k] != 0) { why = "ncclSend(count = 16, the constant taken for ncclUint8) moved more than 16 bytes: the datatype enum of this librccl differs"; ok = false; }
+    }
+    cleanup();
+    return ok;
+}
+}  // namespace
+
 rr_multi* rr_create_multi(const int* devices, int n_devices)
 {
     if (!devices || n_devices < 1 || n_devices > 64) { g_multi_create_error = "rr_create_multi: need 1..64 device indices"; return nullptr; }
@@ -230,6 +295,8 @@ rr_multi* rr_create_multi(const int* devices, int n_devices)
         m->comms.resize((size_t)n_devices, nullptr);
         const ncclResult_t r = g_rccl.CommInitAll(m->comms.data(), n_devices, devices);
         if (r != 0) { g_multi_create_error = std::string("rr_create_multi: ncclCommInitAll: ") + g_rccl.GetErrorString(r); m->comms.clear(); rr_destroy_multi(m); return nullptr; }
+        std::string why;
+        if (!rccl_selftest(m, why)) { g_multi_create_error = "rr_create_multi: RCCL self-test failed: " + why; rr_destroy_multi(m); return nullptr; }
     }
     return m;
 }
@@ -258,6 +325,7 @@ void rr_destroy_multi(rr_multi* m)
 
 const char* rr_multi_last_error(const rr_multi* m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
 int rr_multi_device_count(const rr_multi* m) { return m ? (int)m->ctx.size() : 0; }
+int rr_multi_rccl_version(const rr_multi* m) { return (m && !m->comms.empty()) ? g_rccl.version : 0; }
 rr_ctx* rr_multi_ctx(rr_multi* m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[(size_t)i] : nullptr; }
 
 // ---- replicated state: every setter goes to every device ------------------------------------------------
@@ -544,7 +612,9 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     RRM_TRY_HIP(S.d_imgs.ensure(bytes));
     { const int rc = rr_assemble_frames_device(m->ctx[0], d_cols, n_loc, block_stride, n_frames, frame_stride, S.d_imgs.p, S.streams[0]);
       if (rc) return fail_drained(m, rc, std::string("root: ") + rr_last_error(m->ctx[0])); }
-    RRM_TRY_HIP(hipMemcpyAsync(out_imgs_u8, S.d_imgs.p, bytes, hipMemcpyDeviceToHost, S.streams[0]));
+    // (the library's own copy kernel when the caller's buffer is page-locked, whichever HIP runtime serves the process)
+    { const int rc = rr_copy_to_host_async(m->ctx[0], S.d_imgs.p, out_imgs_u8, bytes, S.streams[0]);
+      if (rc) return fail_drained(m, rc, std::string("root: ") + rr_last_error(m->ctx[0])); }
     RRM_TRY_HIP(hipEventRecord(S.ev_done, S.streams[0]));
 #undef RRM_TRY_HIP
 #undef RRM_TRY_NCCL

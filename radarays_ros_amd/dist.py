@@ -148,26 +148,38 @@ class AzimuthShard:
             s.step_no = self.k - 1
             if self.host_out:
                 if self.strong:          # latency mode: one frame, delivered at once
-                    s.host.copy_(s.images, non_blocking=True)
+                    self._deliver(s)
                     s.host_step_no = s.step_no
                 else:
                     s.host_pending = True
             if s.done is not None:
                 s.done.record(s.stream)
-            if done_event is not None and s.stream is not None:
-                done_event.record(s.stream)
+            if done_event is not None:
+                if s.stream is not None:
+                    done_event.record(s.stream)
+                else:
+                    done_event.record()
         self.last = s
         return s.images
 
+    def _deliver(self, s):
+        """slot.images -> slot.host on the slot's stream: the library's own copy kernel (rr_copy_to_host_async: the delivered
+        rate then does not depend on which engine the process' HIP runtime would pick for a hipMemcpyAsync); a context
+        without it (the mock of the CPU tests) gets torch's copy"""
+        if s.stream is not None and hasattr(self.ctx, "copy_to_host_async"):
+            self.ctx.copy_to_host_async(s.images.data_ptr(), s.host.data_ptr(), s.images.numel(), s.stream.cuda_stream)
+        else:
+            s.host.copy_(s.images, non_blocking=True)
+
     def flush_host(self):
-        """host_out: deliver the images that are still waiting on their slots (plain copies on the slots' streams) and wait
+        """host_out: deliver the images that are still waiting on their slots (copies on the slots' streams) and wait
         for every delivery.  Afterwards slot.host holds the images of step slot.host_step_no for every slot."""
         if not self.host_out:
             return
         for s in self.slots:
             if s.host_pending:
                 with (torch.cuda.stream(s.stream) if s.stream is not None else contextlib.nullcontext()):
-                    s.host.copy_(s.images, non_blocking=True)
+                    self._deliver(s)
                 s.host_pending = False
                 s.host_step_no = s.step_no
         for s in self.slots:

@@ -20,10 +20,10 @@ SYMBOLS = [
     "rr_simulate_batch_columns_carry_device",
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
-    "rr_set_stats_mode", "rr_debug_trace", "rr_get_bvh_info", "rr_get_trace_grid", "rr_get_graph_stats", "rr_set_timing_mode",
+    "rr_set_stats_mode", "rr_debug_trace", "rr_debug_fresnel", "rr_get_bvh_info", "rr_get_trace_grid", "rr_get_graph_stats", "rr_set_timing_mode",
     "rr_get_kernel_time", "rr_get_kernel_samples", "rr_reserve_timing_events",
-    "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_partition", "rr_multi_plan",
-    "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_ctx",
+    "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_copy_to_host_async", "rr_partition", "rr_multi_plan",
+    "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_rccl_version", "rr_multi_ctx",
     "rr_multi_set_mesh", "rr_multi_set_mesh_gpu", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
     "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
     "rr_multi_simulate_batch_async", "rr_multi_wait", "rr_peek_error_bits_async", "rr_get_traversal_shape",
@@ -135,6 +135,7 @@ def lib():
     L.rr_set_timing_mode.argtypes = [vp, C.c_int]
     L.rr_get_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.rr_debug_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+    L.rr_debug_fresnel.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rr_get_trace_grid.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
     L.rr_get_graph_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rr_get_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -143,6 +144,7 @@ def lib():
     L.rr_reserve_timing_events.argtypes = [vp, C.c_size_t]
     L.rr_simulate_batch_host_async.argtypes = [vp, vp, C.c_int, vp, vp]
     L.rr_wait_host.argtypes = [vp, vp]
+    L.rr_copy_to_host_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.rr_host_alloc.restype = vp
     L.rr_host_alloc.argtypes = [C.c_size_t]
     L.rr_host_free.argtypes = [vp]
@@ -157,6 +159,7 @@ def lib():
     L.rr_multi_last_error.restype = C.c_char_p
     L.rr_multi_last_error.argtypes = [vp]
     L.rr_multi_device_count.argtypes = [vp]
+    L.rr_multi_rccl_version.argtypes = [vp]
     L.rr_multi_ctx.restype = vp
     L.rr_multi_ctx.argtypes = [vp, C.c_int]
     L.rr_multi_set_mesh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp]
@@ -335,6 +338,10 @@ class Context:
     def wait_host(self, h_imgs_ptr=None):
         self._ck(self._L.rr_wait_host(self._h, h_imgs_ptr))
 
+    def copy_to_host_async(self, d_src_ptr, h_dst_ptr, nbytes, stream=None):
+        """device -> host on `stream` by the library's own copy kernel (page-locked destination) -- rr_copy_to_host_async"""
+        self._ck(lib().rr_copy_to_host_async(self._h, C.c_void_p(d_src_ptr), C.c_void_p(h_dst_ptr), C.c_size_t(nbytes), C.c_void_p(stream)))
+
     def simulate_batch_columns_device(self, poses, az_begin, az_end, d_cols_u8_ptr, stream=None):
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
         self._ck(self._L.rr_simulate_batch_columns_device(self._h, p.ctypes.data, len(p), az_begin, az_end,
@@ -491,6 +498,20 @@ class Context:
         self._ck(self._L.rr_debug_trace(self._h, o.ctypes.data, d.ctypes.data, len(o), t.ctypes.data, f.ctypes.data))
         return t, f
 
+    def debug_fresnel(self, normals, dirs, energy, v1, v2):
+        """rr_debug_fresnel: the kernels' fresnel_split on n inputs -> (refl_dir [n][3] f32, refl_energy [n] f64, refr_dir, refr_energy)"""
+        nr = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(d)
+        e = np.ascontiguousarray(np.broadcast_to(np.asarray(energy, np.float64), (n,)))
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(v1, np.float64), (n,)))
+        b = np.ascontiguousarray(np.broadcast_to(np.asarray(v2, np.float32), (n,)))
+        rd, td = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        re, te = np.zeros(n, np.float64), np.zeros(n, np.float64)
+        self._ck(self._L.rr_debug_fresnel(self._h, n, nr.ctypes.data, d.ctypes.data, e.ctypes.data, a.ctypes.data, b.ctypes.data,
+                                          rd.ctypes.data, re.ctypes.data, td.ctypes.data, te.ctypes.data))
+        return rd, re, td, te
+
 
 class HostImages:
     """Page-locked host memory for images (rr_host_alloc), viewed as a numpy array."""
@@ -598,6 +619,10 @@ class MultiContext:
     def _ck(self, rc):
         if rc != 0:
             raise RRError("%s (rc=%d)" % (self._L.rr_multi_last_error(self._h).decode(), rc))
+
+    def rccl_version(self):
+        """NCCL version code of the RCCL library behind the communicator (0: none)"""
+        return int(self._L.rr_multi_rccl_version(self._h))
 
     def device_count(self):
         return self._L.rr_multi_device_count(self._h)

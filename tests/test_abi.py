@@ -66,7 +66,7 @@ def test_default_config_matches_reference_cfg(native_lib):
     assert c.n_angles == 400 and abs(c.theta_inc + 2 * 3.141592653589793 / 400) < 1e-8
     assert abs(c.wave_energy_threshold - 0.001) < 1e-9 and c.range_max == 1000.0
     assert c.record_multi_reflection == 1 and c.record_multi_path == 0
-    assert native_lib.lib().rr_abi_version() == 5
+    assert native_lib.lib().rr_abi_version() == 6
 
 
 def test_missing_library_fails_loudly(native_lib, monkeypatch, tmp_path):

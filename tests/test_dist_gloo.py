@@ -289,3 +289,121 @@ def test_bench_keeps_torchs_runtime_unless_asked_and_for_n_above_one(monkeypatch
     monkeypatch.setenv("RR_BENCH_SYSTEM_HIP", "1")
     assert bench.prefer_system_hip_runtime(8).startswith("torch wheel")
     assert bench.prefer_system_hip_runtime(1).startswith("torch wheel")      # torch is already imported here
+
+
+class _BenchMockCtx:
+    """native.Context's surface as bench.main() uses it, with canned counters and columns that only say who rendered them --
+    for the CPU dry run of the N > 1 bench (no oracle: the numbers of a dry run mean nothing, its control flow is the point)."""
+
+    def __init__(self, local_rank):
+        self.rank = local_rank
+        self.calls = {"batch": 0, "carry": 0, "assemble": 0}
+        self.C, self.A = 3424, 400
+
+    def _view(self, ptr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr))
+
+    def set_mesh(self, *a, **k): pass
+    def set_materials(self, *a, **k): pass
+    def set_config(self, cfg, n_angles=400, **k): self.C, self.A = cfg.n_cells, n_angles
+    def set_beam_samples(self, *a): pass
+    def set_noise_offsets(self, *a): pass
+    def set_stats_mode(self, on): pass
+    def set_timing_mode(self, on): pass
+    def reserve_timing_events(self, n): pass
+    def close(self): pass
+    def stats(self): return {"wave_passes": 80000 * 8, "hits": 1, "signals": 1, "nodes_visited": 10 ** 7, "tris_tested": 10 ** 6, "overflow": 0}
+    def traversal_shape(self): return {"waves": 5000, "iterations": 100000, "node_path_issues": 90000, "leaf_path_issues": 30000,
+                                       "live_quad_steps": 1200000, "max_iterations": 60, "node_steps": 900000, "leaf_steps": 300000}
+    def kernel_time(self, name, reset=False): return (1.0, 4)
+
+    def simulate_batch_columns_device(self, poses, b, e, ptr, sp):
+        self.calls["batch"] += 1
+        self._view(ptr, len(poses) * (e - b) * self.C)[:] = 10 + self.rank
+
+    def simulate_batch_columns_carry_device(self, poses, b, e, ptr, sp, src, dst, nbytes):
+        self.calls["carry"] += 1
+        self._view(dst, nbytes)[:] = self._view(src, nbytes)
+        self.simulate_batch_columns_device(poses, b, e, ptr, sp)
+
+    def simulate_columns_device(self, pose, b, e, ptr, f32, sp):
+        self._view(ptr, (e - b) * self.C)[:] = 10 + self.rank
+
+    def assemble_frames_device(self, ptr, n_loc, stride, n_frames, frame_stride, imgs_ptr, sp):
+        self.calls["assemble"] += 1
+        self._view(imgs_ptr, n_frames * self.C * self.A)[:] = 1
+
+    def assemble_image_device(self, ptr, img_ptr, sp):
+        self._view(img_ptr, self.C * self.A)[:] = 1
+
+
+def _worker_bench_dryrun(rank, world, port, out_dir, fail_rank):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank), "RR_BENCH_DRYRUN": "1", "RR_BENCH_ERRDIR": os.path.join(out_dir, "err")})
+    import bench
+
+    def make(local_rank):
+        c = _BenchMockCtx(local_rank)
+        if local_rank == fail_rank:
+            def boom(*a, **k):
+                raise RuntimeError("device %d: wave/signal queue capacity exceeded (injected)" % local_rank)
+            c.simulate_batch_columns_device = boom
+        return c
+    bench.TEST_HOOKS = {"context": make}
+    fd = os.open(os.path.join(out_dir, "stdout_rank%d.txt" % rank), os.O_CREAT | os.O_WRONLY | os.O_TRUNC)
+    os.dup2(fd, 1)                       # what a launcher would see on the rank's stdout
+    try:
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", "config2_100k_400x200_1pass"])
+    except BaseException as exc:         # noqa: BLE001  what `python bench.py` does at top level
+        bench.report_failure(exc)
+        os._exit(7 if rank == fail_rank else 0)       # (the other rank would hang in its collective: a launcher kills it)
+
+
+def test_bench_two_rank_dry_run_prints_the_full_line(tmp_path):
+    """`bench.py --gpus 2` end to end on the CPU: two gloo ranks, a mock context, the REAL main() -- rank / barrier / all_reduce
+    flow, the sharded step loop with host delivery, the rccl block, n1_reference, the line's assembly.  ONE line on rank 0's
+    stdout, nothing on rank 1's."""
+    import json
+    port = _free_port()
+    mp.spawn(_worker_bench_dryrun, args=(2, port, str(tmp_path), -1), nprocs=2, join=True)
+    out0 = open(os.path.join(str(tmp_path), "stdout_rank0.txt")).read().strip().splitlines()
+    assert len(out0) == 1 and open(os.path.join(str(tmp_path), "stdout_rank1.txt")).read().strip() == ""
+    d = json.loads(out0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["frames_per_batch"] == 16
+    r = d["rccl"]
+    assert r["world_size"] == 2 and r["backend"] == "gloo" and len(r["ranks"]) == 2 and len(r["per_rank_images_per_s"]) == 2
+    assert all(x > 0 for x in r["per_rank_images_per_s"]) and r["collective"].startswith("all_to_all_single")
+    assert r["bytes_per_collective"] == 16 * 200 * 3424
+    assert d["n1_reference"] is not None and d["n1_reference"]["source"].startswith("profiles/")
+    assert d["roofline"] is not None and "cpu_baseline" not in d and d["hbm_resident"] is None
+    assert abs(d["value"] - 3 * 32 / (1e-3 * d["ms_per_step"] * 3)) < 1e-6 * d["value"] + 0.01       # value = all ranks' frames / slowest rank's time
+
+
+def test_bench_rank_failure_prints_one_error_line(tmp_path):
+    """a rank that fails inside its step loop -> ONE JSON line carrying "error" (the failing layer's text)
+    and the failing rank, a non-zero exit code; no second line from anybody."""
+    import json
+    port = _free_port()
+    ctx = mp.spawn(_worker_bench_dryrun, args=(2, port, str(tmp_path), 1), nprocs=2, join=False)
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 120 and any(p.is_alive() for p in ctx.processes):
+        if not ctx.processes[1].is_alive():              # the launcher's part: the failed rank takes the others down
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.terminate()
+        time.sleep(0.2)
+    for p in ctx.processes:
+        p.join(10)
+    assert ctx.processes[1].exitcode == 7
+    lines = []
+    for r in (0, 1):
+        lines += [x for x in open(os.path.join(str(tmp_path), "stdout_rank%d.txt" % r)).read().strip().splitlines() if x]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["failing_rank"] == 1 and d["n_gpus"] == 2
+    assert "queue capacity exceeded (injected)" in d["error"] and d["error"].startswith("RuntimeError")
+    rec = json.load(open(os.path.join(str(tmp_path), "err", "rank_1.json")))
+    assert rec["rank"] == 1 and "Traceback" in rec["traceback"]

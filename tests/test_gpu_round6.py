@@ -1,0 +1,191 @@
+"""GPU tests of round 6 (include/radarays_mi355.h, ABI 6):
+  * launch graphs replayed back to back with NO host synchronisation between the calls (advisor, round 5: a replay re-sets
+    the pose node of an exec whose previous launch may still be queued) -- every batch must show ITS poses
+  * host delivery by the library's own copy kernel (rr_copy_to_host_async, k_copy_host): the bytes, whatever its shape
+  * the per-pass history reaches the host through a kernel's stores (no hipMemcpyAsync left in a chain)
+  * k_trace with the root step peeled (RR_ROOT_PRELOAD builds) is covered by the ordinary parity suite: same code path
+"""
+import numpy as np
+import pytest
+
+from common import golden_beams, materials_for
+from radarays_ros_amd import params, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(native_lib, s, cfg, mats, beams, noise=None):
+    c = native_lib.Context(0)
+    c.set_mesh(s["verts"], s["faces"], s["face_object_id"])
+    c.set_materials(mats, s["object_materials"], 0)
+    c.set_config(cfg)
+    c.set_beam_samples(beams)
+    if noise is not None:
+        c.set_noise_offsets(noise)
+    return c
+
+
+@pytest.mark.parametrize("lanes", ["1", "2", "4"])
+def test_graph_replays_back_to_back_show_their_own_poses(native_lib, monkeypatch, lanes):
+    """10 batches of DIFFERENT poses into 10 distinct buffers, issued back to back on one stream without a host wait, twice
+    over (so that every shape is captured and then replayed while earlier replays are still queued): each buffer equals the
+    kernel-by-kernel render (RR_GRAPHS=0) of its own poses.  RR_LANES=1: every replay meets the exec (pair) of the one lane;
+    the batches are heavy enough (8 frames x 400 azimuths x 96 rays x 3 passes) that several are in flight at any time."""
+    import torch
+    s = scenes.heightfield_room(64, n_buildings=40, seed=3)
+    cfg = params.kaist_preset(n_reflections=3, n_samples=96, ambient_noise=2)
+    mats = materials_for(s)
+    beams = golden_beams(96)
+    noise = (np.random.RandomState(11).uniform(0, 1, (8, 400)) * 1000.0).astype(np.float32)
+    P = scenes.trajectory(21, s["name"])                 # 21 poses, windows of 8 at a stride of 2: all batches differ
+    batches = [[P[(2 * k + j) % 21] for j in range(8)] for k in range(10)]
+
+    monkeypatch.setenv("RR_LANES", lanes)
+    monkeypatch.setenv("RR_GRAPHS", "0")
+    c0 = _ctx(native_lib, s, cfg, mats, beams, noise)
+    st = torch.cuda.current_stream().cuda_stream
+    one = torch.zeros((8, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+    want = []
+    for b in batches:
+        c0.simulate_batch_device(b, one.data_ptr(), st)
+        c0.synchronize(st)
+        want.append(one.cpu().numpy().copy())
+    assert c0.graph_stats() == (0, 0)
+    c0.close()
+    assert not np.array_equal(want[0], want[1])
+
+    monkeypatch.delenv("RR_GRAPHS")
+    c = _ctx(native_lib, s, cfg, mats, beams, noise)
+    outs = [torch.zeros((8, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0") for _ in range(10)]
+    for rnd in range(3):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        for k, b in enumerate(batches):                  # no synchronisation in here
+            c.simulate_batch_device(b, outs[k].data_ptr(), st)
+        c.synchronize(st)
+        for k in range(10):
+            assert np.array_equal(outs[k].cpu().numpy(), want[k]), (rnd, k)
+    cap, rep = c.graph_stats()
+    assert cap >= 1 and rep >= 10, (cap, rep)
+    c.close()
+
+
+def test_copy_to_host_async_moves_the_bytes(native_lib, monkeypatch):
+    """rr_copy_to_host_async: page-locked destination -> the copy kernel (any number of workgroups / stores in flight),
+    pageable or misaligned -> hipMemcpyAsync; the same bytes either way."""
+    import torch
+    s = scenes.box12()
+    cfg = params.kaist_preset(n_reflections=1, ambient_noise=0)
+    rng = np.random.RandomState(3)
+    n = 3 * 3424 * 400
+    src = torch.from_numpy(rng.randint(0, 256, n + 64).astype(np.uint8)).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for blocks, inflight in (("1", "1"), ("7", "0"), ("64", "4"), ("1024", "64")):
+        monkeypatch.setenv("RR_FLUSH_BLOCKS", blocks)
+        monkeypatch.setenv("RR_FLUSH_INFLIGHT", inflight)
+        c = _ctx(native_lib, s, cfg, params.kaist_materials(), golden_beams(16))
+        h = native_lib.HostImages((n + 64,))
+        for off, nb in ((0, n), (16, 4096), (0, 16), (32, n - 32), (16, 1000), (3, 1000), (0, 0)):     # (16, 1000) / (3, 1000): not multiples of 16 / misaligned
+            h.array[:] = 0
+            c.copy_to_host_async(src.data_ptr() + off, h.ptr + off, nb, st)
+            c.synchronize(st)
+            assert np.array_equal(h.array[off:off + nb], src[off:off + nb].cpu().numpy()), (blocks, inflight, off, nb)
+            assert not h.array[off + nb:].any() and not h.array[:off].any()
+        pageable = np.zeros(n, np.uint8)
+        c.copy_to_host_async(src.data_ptr(), pageable.ctypes.data, n, st)
+        c.synchronize(st)
+        assert np.array_equal(pageable, src[:n].cpu().numpy())
+        h.close(); c.close()
+
+
+@pytest.mark.parametrize("passes", [1, 3])
+@pytest.mark.parametrize("flush", [("1", "8", "1"), ("1", "64", "0"), ("0", "32", "4")])
+def test_host_delivery_through_the_copy_kernel(native_lib, monkeypatch, passes, flush):
+    """rr_simulate_batch_host_async with one pass (no later-pass launch a copy could ride on: every batch leaves through
+    k_copy_host at the lane's next use or at rr_wait_host) and with three (trickle + the flush at the end), under several
+    shapes of the copy kernel and with it switched off (RR_FLUSH_KERNEL=0: hipMemcpyAsync): the images of rr_simulate."""
+    import torch
+    monkeypatch.setenv("RR_FLUSH_KERNEL", flush[0]); monkeypatch.setenv("RR_FLUSH_BLOCKS", flush[1]); monkeypatch.setenv("RR_FLUSH_INFLIGHT", flush[2])
+    s = scenes.heightfield_room(64, n_buildings=40, seed=3)
+    cfg = params.kaist_preset(n_reflections=passes, n_samples=60, ambient_noise=2)
+    noise = (np.random.RandomState(5).uniform(0, 1, 400) * 1000.0).astype(np.float32)
+    poses = scenes.trajectory(6, s["name"])
+    c = _ctx(native_lib, s, cfg, materials_for(s), golden_beams(60), noise)
+    ref = [c.simulate(p)[0] for p in poses]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    NB = 18
+    bufs = [native_lib.HostImages((4, cfg.n_cells, 400)) for _ in range(NB)]
+    for b in bufs:
+        b.array[:] = 9
+    for k in range(NB):
+        c.simulate_batch_host_async([poses[(k + j) % 6] for j in range(4)], bufs[k].ptr, streams[k % 4].cuda_stream)
+    for k in (NB - 1, 0, 7, 16):
+        c.wait_host(bufs[k].ptr)
+        for j in range(4):
+            assert np.array_equal(bufs[k].array[j], ref[(k + j) % 6]), (k, j)
+    c.wait_host(None)
+    for k in range(NB):
+        for j in range(4):
+            assert np.array_equal(bufs[k].array[j], ref[(k + j) % 6]), (k, j)
+    c.synchronize()
+    for b in bufs:
+        b.close()
+    c.close()
+
+
+def test_trace_row_history_reaches_the_host_without_a_copy_call(native_lib, monkeypatch):
+    """The per-pass history (GridHint) is stored into its page-locked host copy by the chain's k_column: after a few batches
+    the rows a lane launches are tightened (rr_get_trace_grid), exactly as when a 96-byte hipMemcpyAsync carried it."""
+    import torch
+    s = scenes.heightfield_room(64, n_buildings=40, seed=3)
+    cfg = params.kaist_preset(n_reflections=4, n_samples=64, ambient_noise=0)
+    c = _ctx(native_lib, s, cfg, materials_for(s), golden_beams(64))
+    poses = scenes.trajectory(8, s["name"])
+    imgs = torch.zeros((8, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(6):
+        c.simulate_batch_device(poses, imgs.data_ptr(), st)
+        c.synchronize(st)
+    rows, hist, repaired = c.trace_grid()
+    assert hist[1] > 0 and hist[2] > 0 and hist[3] > 0, hist
+    full = [(64 << p) // 16 for p in range(4)]
+    assert any(0 < rows[p] < full[p] for p in (1, 2, 3)), (rows, full)      # at least one pass runs tightened rows
+    c.close()
+
+
+def test_gpu_fresnel_split_against_the_oracle_on_the_reference_derived_cases(native_lib, oracle):
+    """The kernels' fresnel_split (rr_debug_fresnel) on the 11,000 cases of tests/golden/pyref_cases.py -- the inputs whose
+    reference-python outputs pin the oracle in tests/test_oracle_dense_pin.py (v1 != 0.3, v2 > v1, the angle-limit branch,
+    both eps branches): reflection directions bit for bit (pure un-fused f32 arithmetic); the transmitted / totally-reflected
+    decision identical; refraction directions bit for bit except where the last ulp of the f64 cos / sqrt (GPU libm against
+    the host's) flips the f32 rounding (< 0.5 % of the cases, one ulp); energies to 1e-12 wherever the refraction direction is
+    bit-equal (the refraction ANGLE is acosf of that direction: one f32 ulp of it is a different angle), NaN where the oracle
+    has NaN (the reference's acosf(> 1) at near-normal incidence)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import pyref_cases
+    c = native_lib.Context(0)
+    tot = flips = 0
+    for fam in pyref_cases.FAMILIES:
+        th, v1, v2 = pyref_cases.cases(fam)
+        D = pyref_cases.direction(th)
+        Nn = np.tile(np.array([[-1.0, 0.0, 0.0]], np.float32), (len(th), 1))
+        rd, re, td, te = c.debug_fresnel(Nn, D, 1.0, v1, v2.astype(np.float32))
+        o = [oracle.fresnel((-1.0, 0.0, 0.0), D[i], 1.0, 0.5, float(v1[i]), float(v2[i])) for i in range(len(th))]
+        ord_, ore, otd, ote = (np.array([x[k] for x in o]) for k in range(4))
+        assert np.array_equal(rd.view(np.uint32), ord_.astype(np.float32).view(np.uint32)), fam
+        assert np.array_equal(np.any(td != 0, axis=1), np.any(otd != 0, axis=1)), fam
+        same = np.all(td.view(np.uint32) == otd.astype(np.float32).view(np.uint32), axis=1)
+        assert np.abs(td - otd).max() <= 1.3e-7 * max(1.0, float(np.abs(otd).max())), (fam, np.abs(td - otd).max())
+        flips += int((~same).sum()); tot += len(th)
+        nan_o, nan_g = np.isnan(ore), np.isnan(re)
+        assert np.array_equal(nan_o[same], nan_g[same]), fam
+        ok = same & ~nan_o
+        assert np.abs(re[ok] - ore[ok]).max() < 1e-12 and np.abs(te[ok] - ote[ok]).max() < 1e-12, (fam, np.abs(re[ok] - ore[ok]).max())
+        # a scaled energy scales both results (radar_algorithms.h:135-136)
+        rd2, re2, td2, te2 = c.debug_fresnel(Nn, D, 0.37, v1, v2.astype(np.float32))
+        assert np.allclose(re2[ok], 0.37 * re[ok], rtol=1e-14, atol=0) and np.array_equal(td2, td)
+    assert flips <= 0.005 * tot, (flips, tot)
+    c.close()
