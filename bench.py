@@ -507,7 +507,13 @@ def main(argv=None):
     finish_main(); tc.synchronize()
     # (RR_BENCH_LIVE_TIMING=0: a diagnostic -- the timed region without the begin / end events around its k_trace launches;
     # roofline.frac then falls back to the isolated launch time and says so)
-    live_timing = os.environ.get("RR_BENCH_LIVE_TIMING", "1") != "0"
+    # The events exist to time the DOMINANT kernel live (roofline.achieved); they are taken only when that kernel is a k_trace
+    # launch.  Where another kernel dominates (config 2: k_column) they would buy nothing and they are not free there: the
+    # chains of a one-pass workload are then issued kernel by kernel instead of being replayed from launch graphs, 34.7k ->
+    # 27.8k images/s on config 2 (round 6, same box) -- that was the "regression" of the round-5 line (30.9k against the 39.0k
+    # round 4 had measured in an untimed extra region)
+    live_timing = os.environ.get("RR_BENCH_LIVE_TIMING", "1") != "0" and dominant in ("trace", "trace0")
+    graphs_before = ctx.graph_stats() if hasattr(ctx, "graph_stats") else (0, 0)
     ctx.set_timing_mode(2 if live_timing else 0)
     ctx.kernel_time("trace", reset=True); ctx.kernel_time("trace0", reset=True); ctx.kernel_time("trace_repair", reset=True)
     if world > 1:
@@ -525,6 +531,7 @@ def main(argv=None):
     t1 = time.perf_counter()
     live = {n: ctx.kernel_time(n, reset=True) for n in ("trace", "trace0", "trace_repair")}
     ctx.set_timing_mode(0)
+    graphs_after = ctx.graph_stats() if hasattr(ctx, "graph_stats") else (0, 0)
     # ---- contention: every kernel's duration while `slots` batches share the chip (outside the timed region: stream events
     # around every launch keep the launch graphs off and cost host time) against its duration alone (`iso` above)
     live_all = None
@@ -839,6 +846,13 @@ def main(argv=None):
             "weak_scaling_proxy": wproxy,
             "roofline": roof,
             "contention": contention,
+            "launch_graphs": {"replays_in_timed_region": int(graphs_after[1] - graphs_before[1]),
+                              "captures_in_timed_region": int(graphs_after[0] - graphs_before[0]),
+                              "live_timing_events": bool(live_timing),
+                              "what": "chains replayed from hipGraphs inside the timed region.  0 on the multi-pass workloads by construction: "
+                                      "their chains carry the previous batch's host copy on their trace launches (pointers that move from "
+                                      "call to call) and, when the dominant kernel is a k_trace launch, begin / end events -- both are "
+                                      "issued kernel by kernel; `hbm_resident` and `single_pose` replay graphs"},
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -152,8 +152,9 @@ int rr_set_noise_offsets(rr_ctx* ctx, const float* rnd, size_t n);
  * rr_simulate* call uses poses[azimuth] and ignores its own pose argument (which must still
  * be a valid pose).  n = 0 switches back to one pose per frame.  For the batch entry points n may be
  * k * n_angles (k tables, one sweep of the antenna each): frame f of a batch then uses table f % k, like the
- * rows of rr_set_noise_offsets -- the reference's default mode through the batched / multi-GPU path.  (A parameter
- * batch renders every set with table 0.) */
+ * rows of rr_set_noise_offsets -- the reference's default mode through the batched / multi-GPU path.  A pose batch of
+ * more than one frame while exactly ONE table is set is refused (-3): every frame would be the same sweep and the call's
+ * poses would be ignored silently.  (A parameter batch renders every set with table 0.) */
 int rr_set_motion_poses(rr_ctx* ctx, const float* poses, size_t n);
 
 /* RadarCPU::simulate for azimuths [az_begin, az_end) with sensor pose
@@ -204,7 +205,11 @@ int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint
  * Whole frames of n_frames poses like rr_simulate_batch_device, delivered to the caller's host buffer
  * h_imgs_u8 = [n_frames][n_cells][n_angles].  Returns at once; the images are COMPLETE ONLY after rr_wait_host(ctx,
  * h_imgs_u8) (NULL: every outstanding buffer) or rr_synchronize() -- until then the buffer must stay valid and must not be
- * read.  How the bytes travel is the library's business: a batch's images wait in device memory and ride out on the
+ * read.  How the bytes travel is the library's business.  By default they leave at once over the SDMA engines, submitted
+ * through ROCr by a worker thread of the context behind the batch's last kernel (csrc/rr_sdma.cpp): no shader core stores a byte
+ * of them, and it is the same engine whichever HIP runtime serves the process (the runtime inside the PyTorch wheel would
+ * carry a hipMemcpyAsync as a blit kernel: 27-35k images/s on config 2 where SDMA delivers the link's 39k).  Where that path
+ * is not available (RR_HOST_SDMA=0, a pageable buffer, no reachable ROCr) a batch's images wait in device memory and ride out on the
  * trace launches of the next batch that uses the same frame lane (a few waves trickle them over PCIe with one store in
  * flight each, which keeps the stores of the running kernels from queueing behind them: within 1 % of the rate with the
  * images left in HBM, where a plain copy behind each batch costs 7 %); rr_wait_host / rr_synchronize / any other use of
@@ -465,17 +470,32 @@ typedef struct rr_mesh {
                                    what to match a scene's material table against */
 } rr_mesh;
 int rr_load_mesh_file(const char* path, rr_mesh* out, char* err, size_t err_len);
+/* Object numbering.  The reference indexes its material table by the object id rmagine's importer hands out
+ * (m_object_materials[obj_id], RadarCPU.cpp:268; rm::import_embree_map, radar_simulator.cpp:149; the per-object lists of
+ * config/oru4_test.yaml:37-56).  rr_load_mesh_file numbers objects in DEPTH-FIRST SCENE ORDER (OBJ: order of the o / g
+ * groups; DAE: instantiated geometries as the visual scene is walked) -- this build's specification; whether rmagine / assimp
+ * number a given file the same way cannot be checked without them.  A scene whose material list was written for another
+ * numbering is put right here: object `order[k]` becomes id k, objects not listed keep their relative order behind the listed
+ * ones; only face_object_id and the order of object_names change.  Unknown, duplicate or ambiguous names are refused. */
+int rr_mesh_reorder_objects(rr_mesh* m, const char* const* order, size_t n_order, char* err, size_t err_len);
 void rr_free_mesh(rr_mesh* m);
 
 /* ---- environment switches (read at rr_create / at a build; none is needed in normal use) --------------------------
  * RR_LANES (4)            frame buffer sets = batches that can be in flight (1..8)
  * RR_STREAM_LANES (3)     lanes whose own stream rr_simulate_device rotates over
+ * RR_STACKLESS (0)        1: k_trace walks the tree WITHOUT a stack (parent links, a node re-fetched each time the walk returns to it;
+ *                         no LDS) -- the traversal north_star names, built and measured in round 6: same images, slower
  * RR_COPY_BLOCKS (8)      one-wave workgroups of a trace launch that trickle a deferred host copy; 0: never fold
+ * RR_HOST_SDMA (1)         rr_simulate_batch_host_async hands a batch's images to the SDMA engines through ROCr (hsa_amd_memory_async_copy,
+ *                         a worker thread per context; page-locked destinations) -- the same engine under every HIP runtime; 0: the
+ *                         deferred copies below (trickled out by the next batch's trace launches / the copy kernel).  RR_HOST_SDMA_VERBOSE=1
+ *                         says on stderr why the path was not available or was switched off
+ * RR_HOST_COPY_STREAM (0) 1: one-pass frames (nothing later could carry their images) are copied out at once on one dedicated stream
  * RR_FLUSH_KERNEL (1)     a host copy that does not ride on a trace launch (one-pass frames, the end of a run, rr_copy_to_host_async)
  *                         is stored by the library's own kernel when the destination is page-locked; 0: hipMemcpyAsync
  * RR_FLUSH_BLOCKS (32)    ... its one-wave workgroups
  * RR_FLUSH_INFLIGHT (4)   ... 1-KB stores a wave keeps outstanding (0: no limit)
- * RR_FLUSH_THREADS (64)   ... threads per workgroup (64..1024); RR_FLUSH_NT (0): nontemporal stores
+ * RR_FLUSH_THREADS (64)   ... threads per workgroup (64..1024); RR_FLUSH_UNROLL (1): 16-byte loads a lane keeps in flight (1, 2, 4, 8)
  * RR_FLUSH_XCD (0)        ... the XCD all of them run on (PCIe-paced stores then fill the write queues of one XCD only); -1: all eight
  * RR_FOLD_MIN_BUSY (2)    other lanes that must be busy for a host copy to be folded into the next batch
  * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)

@@ -27,7 +27,9 @@ public:
 
     // Same first five arguments as RadarCPU / RadarGPU (RadarCPU.hpp:21-28).  The map: rr_load_mesh_file reads what
     // rm::import_embree_map reads for the node (src/radar_simulator.cpp:149) -- .ply, .obj, .dae; object ids (the index into
-    // `object_materials`) follow the scene's depth-first order.  `devices`: the GPUs of this node the backend fans out over
+    // `object_materials`) follow the scene's depth-first order -- an ASSUMPTION about rmagine's numbering that cannot be checked
+    // here; private parameter ~hip_object_order (list of object names) renumbers them, and the second constructor takes any
+    // numbering the caller already holds.  `devices`: the GPUs of this node the backend fans out over
     // (azimuth blocks, one RCCL gather per frame).  `build_on_gpu`: LBVH built on device 0 (a 10M-triangle map loads in 0.35 s
     // instead of 1.9 s; frames take 1.2x as long).
     RadarHIP(

@@ -41,6 +41,22 @@ RadarHIP::RadarHIP(
     {
         throw std::runtime_error(std::string("[RadarHIP] map '") + map_file + "': " + err);
     }
+    // Object ids index the material list (m_object_materials[obj_id], RadarCPU.cpp:268).  The loader numbers objects in
+    // depth-first scene order; whether rm::import_embree_map (radar_simulator.cpp:149) numbers this file the same way cannot be
+    // known without rmagine.  ~hip_object_order: the object NAMES in the order the material list of the scene's yaml was
+    // written for (config/oru4_test.yaml:37-56) -- the objects are renumbered to it (rr_mesh_reorder_objects)
+    std::vector<std::string> object_order;
+    nh_p->getParam("hip_object_order", object_order);
+    if(!object_order.empty())
+    {
+        std::vector<const char*> names;
+        for(size_t i = 0; i < object_order.size(); i++) { names.push_back(object_order[i].c_str()); }
+        if(rr_mesh_reorder_objects(&mesh, names.data(), names.size(), err, sizeof(err)))
+        {
+            rr_free_mesh(&mesh);
+            throw std::runtime_error(std::string("[RadarHIP] ~hip_object_order: ") + err);
+        }
+    }
     std::cout << "[RadarHIP] " << map_file << ": " << mesh.n_faces << " triangles, " << mesh.n_objects << " objects" << std::endl;
     for(size_t i = 0; mesh.object_names && i < mesh.n_objects; i++)
     {

@@ -4,6 +4,7 @@
 #include "../../include/radarays_mi355.h"
 #include "rr_device.h"
 #include "rr_hostprof.h"
+#include "rr_sdma.h"
 
 #include <algorithm>
 #include <cmath>
@@ -33,10 +34,10 @@ void launch_debug_trace(const Params& P, const float* origs, const float* dirs, 
                         float* out_t, uint32_t* out_face, hipStream_t s, unsigned long long* steps = nullptr);
 void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s, size_t n_tris);
 void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStream_t s);
-void* trace0_kernel(bool spill);
+void* trace0_kernel(bool spill, bool stackless);
 Params trace0_params(const Params& P);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
-void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int nt);
+void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int unroll);
 void launch_frame_report(const Counters* cnt, const SegStats* ss, size_t n_ss, void* h_dst, hipStream_t s);
 void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s);
 void launch_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
@@ -132,6 +133,9 @@ struct Lane {
     // a batch's images stay in d_img_u8 ("deferred") until the lane's NEXT host-delivery batch, whose later-pass trace
     // launches carry the copy (see Params::copy_src); rr_wait_host / rr_synchronize / any other use of the lane flush a
     // deferred copy with a plain hipMemcpyAsync
+    // ... or, the default: the batch's images leave at once over SDMA (rr_sdma.cpp), job `sdma_job` (0: none) into `sdma_dst`;
+    // the lane's next user waits for the job on the host before it lets anything overwrite d_img_u8
+    uint64_t sdma_job = 0; const void* sdma_dst = nullptr;
     bool deferred = false;
     uint8_t* def_dst = nullptr; size_t def_bytes = 0; hipStream_t def_stream = nullptr; bool def_foldable = false;
 };
@@ -206,14 +210,23 @@ struct rr_ctx {
     bool roctx = false;
     int fold_min_busy = 2;       // other lanes that must have a batch in flight for a host copy to be folded (RR_FOLD_MIN_BUSY)
     int seg_chunk = 16;          // later-pass trace grids in chunks of S neighbouring segments, segment-fast inside a chunk (RR_TRACE_CHUNK; 0: rows of one segment)
+    int stackless = 0;           // RR_STACKLESS=1: the stack-free traversal (no LDS; DESIGN.md §3 says what it costs)
     int cull_pop = 1;            // k_trace's later passes drop stack entries at pop time (RR_CULL_POP=0: off; the images are the same either way)
     // a deferred host copy that cannot ride on a later-pass trace launch (one-pass frames, the last batch of a run, a caller
     // with a single batch in flight) is stored by the library's own kernel (k_copy_host) when the destination is page-locked:
     // flush_blocks one-wave workgroups with at most flush_inflight 1-KB stores outstanding each (RR_FLUSH_BLOCKS, RR_FLUSH_INFLIGHT;
     // RR_FLUSH_KERNEL=0: hipMemcpyAsync, i.e. whichever engine the process' HIP runtime picks)
     int flush_kernel = 1, flush_blocks = 32, flush_inflight = 4;
-    int flush_threads = 64, flush_nt = 0;     // threads per workgroup of the copy kernel (RR_FLUSH_THREADS), nontemporal stores (RR_FLUSH_NT)
+    int flush_threads = 64, flush_unroll = 1;  // threads per workgroup of the copy kernel (RR_FLUSH_THREADS), 16-byte loads per lane in flight (RR_FLUSH_UNROLL)
     int flush_xcd = 0;           // the copy kernel's workgroups all on this XCD (RR_FLUSH_XCD 0..7; -1: dealt out over all eight)
+    // RR_HOST_COPY_STREAM=1 (experiment, round 6): a batch that cannot fold its predecessor's images into a trace launch (one-pass
+    // frames) sends its OWN images at once on one dedicated copy stream -- copies then run one at a time, in order, beside the
+    // batches instead of in front of the lane's next one
+    int host_copy_stream = 0; hipStream_t copy_stream = nullptr;
+    // RR_HOST_SDMA (1): rr_simulate_batch_host_async hands a batch's images to ROCr's SDMA path (rr_sdma.cpp: one worker thread,
+    // copies in order, each behind its batch's last kernel) instead of a copy the HIP runtime would pick an engine for; 0, a
+    // pageable destination or a runtime ROCr cannot be reached through: the deferred / trickled copies below
+    int host_sdma = 1; SdmaCopier* sdma = nullptr; bool sdma_tried = false;
     int copy_blocks = 8;         // workgroups (one wave each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
     int tight_grid = 1;          // later-pass trace rows sized by what earlier batches needed (RR_TIGHT_GRID=0: the doubling bound)
     int tight_force = 0;         // RR_TIGHT_FORCE=n: rows of n workgroups whatever the history says (tests of the repair path)
@@ -580,7 +593,7 @@ void fill_params(rr_ctx* c, Lane& L, Params& P, const float pose[7], int az_begi
     P.spill_stride = L.spill_stride; P.stack_lds = L.stack_lds;
     P.spill_depth = std::max(0, (int)c->stack_need - L.stack_lds);
     P.pass0_az = c->pass0_az;
-    P.cull_pop = c->cull_pop; P.seg_chunk = c->seg_chunk;
+    P.cull_pop = c->cull_pop; P.seg_chunk = c->seg_chunk; P.stackless = c->stackless;
     P.grid_hint = L.d_hint.p; P.ovf_list = L.d_ovf_list.p; P.ovf_stride = L.ovf_stride;     // rows stay at the bound until run_frame tightens them
     P.hist_host = (c->tight_grid && g.n_reflections > 1) ? L.h_hist : nullptr;              // the chain's k_column stores the history there (read without a fence by later batches)
 }
@@ -601,7 +614,7 @@ int copy_out(rr_ctx* c, const void* d_src, void* h_dst, size_t bytes, bool visib
 {
     if (bytes == 0) return 0;
     if (c->flush_kernel && visible && bytes % 16 == 0 && ((uintptr_t)h_dst | (uintptr_t)d_src) % 16 == 0) {
-        launch_copy_host(d_src, h_dst, bytes, c->flush_blocks, c->flush_inflight, c->flush_xcd, s, c->flush_threads, c->flush_nt);
+        launch_copy_host(d_src, h_dst, bytes, c->flush_blocks, c->flush_inflight, c->flush_xcd, s, c->flush_threads, c->flush_unroll);
         RR_HIP(c, hipGetLastError());
     } else RR_HIP(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
     return 0;
@@ -615,8 +628,17 @@ bool host_visible(const void* p)
 }
 
 // the lane's deferred host copy, now, as a plain copy on the stream its batch ran on
+// the images the lane's last host-delivery batch handed to the SDMA worker have left d_img_u8 (host wait; over long before a
+// lane comes round again)
+void settle_sdma(rr_ctx* c, Lane& L)
+{
+    if (L.sdma_job && c->sdma) sdma_wait(c->sdma, L.sdma_job);
+    L.sdma_job = 0; L.sdma_dst = nullptr;
+}
+
 int flush_deferred(rr_ctx* c, Lane& L)
 {
+    settle_sdma(c, L);
     if (!L.deferred) return 0;
     Lane::CopyRec* r = nullptr;
     int rc = take_rec(c, L, &r); if (rc) return rc;
@@ -696,6 +718,10 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
     if (n_frames < 1 || n_frames > RR_MAX_BATCH) return fail(c, -3, "frame batch must be 1..64");
     for (int k = 0; k < 7 * (d_matsets ? 1 : n_frames); k++) if (!std::isfinite(pose[k])) return fail(c, -3, "non-finite pose");
     int rc = upload_tables(c); if (rc) return rc;
+    // ONE per-azimuth pose table and several frames: every frame would be the same sweep and the call's poses would be ignored
+    // without a word (advisor, round 5) -- a batch under include_motion brings one table per frame (or k tables, frame f -> f % k)
+    if (!d_matsets && n_frames > 1 && !c->motion.empty() && c->motion_rows == 1)
+        return fail(c, -3, "a pose batch while ONE per-azimuth pose table is set (rr_set_motion_poses): give one table per frame (k x n_angles poses) or clear the table");
     rc = prepare_lane(c, L, n_seg, lane_f32); if (rc) return rc;
     if (!d_cols_u8) d_cols_u8 = L.d_cols_u8.p;       // the lane's own column buffer, valid only from here on
     if (lane_f32) d_cols_f32 = L.d_cols_f32.p;
@@ -828,7 +854,7 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
                         for (hipGraphNode_t nd : nodes) {
                             hipGraphNodeType ty; hipKernelNodeParams kp{};
                             if (hipGraphNodeGetType(nd, &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
-                                hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == trace0_kernel(P.spill_depth > 0)) {
+                                hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess && kp.func == trace0_kernel(P.spill_depth > 0, P.stackless != 0)) {
                                 fg->pose_node = nd; fg->pose_kp = kp; fg->pose_P = trace0_params(P); break;
                             }
                         }
@@ -931,15 +957,18 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_ROCTX") && atoi(getenv("RR_ROCTX")) != 0) c->roctx = roctx_load();
     if (getenv("RR_FOLD_MIN_BUSY")) c->fold_min_busy = std::max(0, atoi(getenv("RR_FOLD_MIN_BUSY")));
     if (getenv("RR_CULL_POP")) c->cull_pop = atoi(getenv("RR_CULL_POP")) != 0;
+    if (getenv("RR_STACKLESS")) c->stackless = atoi(getenv("RR_STACKLESS")) != 0;
     if (getenv("RR_TRACE_CHUNK")) c->seg_chunk = std::max(0, std::min(1024, atoi(getenv("RR_TRACE_CHUNK"))));
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
     if (getenv("RR_GRAPHS")) c->use_graphs = atoi(getenv("RR_GRAPHS")) != 0;
     if (getenv("RR_FLUSH_KERNEL")) c->flush_kernel = atoi(getenv("RR_FLUSH_KERNEL")) != 0;
+    if (getenv("RR_HOST_COPY_STREAM")) c->host_copy_stream = atoi(getenv("RR_HOST_COPY_STREAM"));
+    if (getenv("RR_HOST_SDMA")) c->host_sdma = atoi(getenv("RR_HOST_SDMA")) != 0;
     if (getenv("RR_FLUSH_BLOCKS")) c->flush_blocks = std::max(1, std::min(1024, atoi(getenv("RR_FLUSH_BLOCKS"))));
     if (getenv("RR_FLUSH_INFLIGHT")) c->flush_inflight = std::max(0, std::min(64, atoi(getenv("RR_FLUSH_INFLIGHT"))));
     if (getenv("RR_FLUSH_XCD")) c->flush_xcd = std::max(-1, std::min(7, atoi(getenv("RR_FLUSH_XCD"))));
     if (getenv("RR_FLUSH_THREADS")) c->flush_threads = std::max(64, std::min(1024, atoi(getenv("RR_FLUSH_THREADS"))));
-    if (getenv("RR_FLUSH_NT")) c->flush_nt = atoi(getenv("RR_FLUSH_NT")) != 0;
+    if (getenv("RR_FLUSH_UNROLL")) c->flush_unroll = std::max(1, std::min(8, atoi(getenv("RR_FLUSH_UNROLL"))));
     if (getenv("RR_TIGHT_GRID")) c->tight_grid = atoi(getenv("RR_TIGHT_GRID")) != 0;
     if (getenv("RR_TIGHT_FORCE")) c->tight_force = std::max(0, atoi(getenv("RR_TIGHT_FORCE")));
     {   // the one angle of total reflection that does not depend on the material table
@@ -969,6 +998,7 @@ void rr_destroy(rr_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();   // frames may still be in flight on the lanes' or the caller's streams
+    if (c->sdma) { sdma_destroy(c->sdma); c->sdma = nullptr; }      // (its queued copies wait for events that have completed by now)
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release(); c->d_mat_limits.release();
@@ -987,6 +1017,7 @@ void rr_destroy(rr_ctx* c)
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_frame) (void)hipHostFree(c->h_frame);
     delete c;
 }
@@ -1405,6 +1436,7 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     Lane& L = c->lanes[li];
     c->last_lane = li;
     const size_t bytes = (size_t)n_frames * g.n_cells * g.n_angles;
+    settle_sdma(c, L);
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));   // the lane's previous batch, incl. its assemble
     // the images the lane's previous batch left behind ride on this batch's later-pass launches when possible
     // ... and worthwhile: the trickle (one 1-KB store per wave in flight, a few waves) needs about 1 ms per launch for 8
@@ -1452,6 +1484,37 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     // next batch and trickled out by a few waves of its later-pass trace launches with ONE store per wave in flight
     // (k_trace, Params::copy_src): 3,980-4,025 images/s, within 1 % of the HBM-resident rate.
     const bool device_visible = host_visible(h_imgs_u8);
+    // The default route: over the SDMA engines through ROCr, at once, behind this batch's assemble (ev_consumed) -- no shader
+    // core stores a byte of it, so nothing has to be deferred or trickled, and it is the same engine under every HIP runtime
+    if (c->host_sdma && device_visible && !c->stats_mode) {
+        if (!c->sdma && !c->sdma_tried) {
+            c->sdma_tried = true;
+            std::string why;
+            c->sdma = sdma_create(c->device, L.d_img_u8.p, why);
+            if (!c->sdma && getenv("RR_HOST_SDMA_VERBOSE")) fprintf(stderr, "[rr] SDMA delivery not available: %s\n", why.c_str());
+        }
+        if (c->sdma && sdma_failed(c->sdma, nullptr)) {
+            if (getenv("RR_HOST_SDMA_VERBOSE")) { std::string why; (void)sdma_failed(c->sdma, &why); fprintf(stderr, "[rr] SDMA delivery switched off: %s\n", why.c_str()); }
+            c->host_sdma = 0;
+        } else if (c->sdma) {
+            L.sdma_job = sdma_submit(c->sdma, L.ev_consumed, L.d_img_u8.p, h_imgs_u8, bytes);
+            L.sdma_dst = h_imgs_u8;
+            return 0;
+        }
+    }
+    if (c->host_copy_stream && g.n_reflections < 2) {
+        // nothing later could carry these images: out they go now, on the copy stream, behind this batch's assemble; the lane's
+        // next batch waits for the copy (device side) before it touches the lane
+        if (!c->copy_stream) RR_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        Lane::CopyRec* r = nullptr;
+        rc = take_rec(c, L, &r); if (rc) return rc;
+        RR_HIP(c, hipStreamWaitEvent(c->copy_stream, L.ev_consumed, 0));
+        rc = copy_out(c, L.d_img_u8.p, h_imgs_u8, bytes, device_visible, c->copy_stream); if (rc) return rc;
+        RR_HIP(c, hipEventRecord(r->ev, c->copy_stream));
+        r->dst = h_imgs_u8; r->pending = true;
+        RR_HIP(c, hipEventRecord(L.ev_consumed, c->copy_stream));      // what the lane's next user waits for
+        return 0;
+    }
     L.deferred = true; L.def_dst = h_imgs_u8; L.def_bytes = bytes; L.def_stream = s; L.def_foldable = device_visible;
     return 0;
 }
@@ -1466,6 +1529,7 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
     const size_t nl = c->lanes.size();
     for (size_t k = 0; k < nl; k++) {
         Lane& L = c->lanes[(c->next_lane + k) % nl];
+        if (L.sdma_job && (h_imgs_u8 == nullptr || L.sdma_dst == h_imgs_u8)) settle_sdma(c, L);
         if (L.deferred && (h_imgs_u8 == nullptr || L.def_dst == h_imgs_u8)) { int rc = flush_deferred(c, L); if (rc) return rc; }
         for (Lane::CopyRec& r : L.rec)
             if (r.pending && (h_imgs_u8 == nullptr || r.dst == h_imgs_u8)) {

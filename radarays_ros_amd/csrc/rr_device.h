@@ -178,6 +178,7 @@ struct Params {
     // frame), and inside a chunk the SEGMENT is the fast dimension: the workgroups that run at the same time hold the same trace
     // positions of neighbouring azimuths, and a segment stays on ONE XCD (S a multiple of 8).  0: one row of the grid per segment
     int seg_chunk;
+    int stackless;           // RR_STACKLESS=1: k_trace walks the tree without a stack (traverse_stackless: parent links, nodes re-fetched on the way up; no LDS) -- a measured alternative, not the default
     int cull_pop;            // later passes / rr_debug_trace: drop stack entries at pop time by their 16-bit distance bound (0: off, RR_CULL_POP=0)
     // tight later-pass trace grids (GridHint above)
     GridHint* grid_hint;     // per lane; null: off

@@ -345,6 +345,34 @@ int rr_load_mesh_file(const char* path, rr_mesh* out, char* err, size_t err_len)
     return 0;
 }
 
+int rr_mesh_reorder_objects(rr_mesh* m, const char* const* order, size_t n_order, char* err, size_t err_len)
+{
+    if (!m || (n_order && !order)) { set_err(err, err_len, "rr_mesh_reorder_objects: null argument"); return -3; }
+    if (n_order == 0) return 0;
+    if (!m->object_names) { set_err(err, err_len, "rr_mesh_reorder_objects: the mesh carries no object names (PLY?)"); return -3; }
+    const size_t n = m->n_objects;
+    std::vector<uint32_t> new_id(n, 0xFFFFFFFFu);
+    uint32_t next = 0;
+    for (size_t k = 0; k < n_order; k++) {
+        if (!order[k]) { set_err(err, err_len, "rr_mesh_reorder_objects: null name"); return -3; }
+        size_t hit = n;
+        for (size_t i = 0; i < n; i++) if (std::strcmp(m->object_names[i], order[k]) == 0) { if (hit != n) { set_err(err, err_len, std::string("rr_mesh_reorder_objects: the mesh has two objects named '") + order[k] + "'"); return -3; } hit = i; }
+        if (hit == n) { set_err(err, err_len, std::string("rr_mesh_reorder_objects: no object named '") + order[k] + "' in the mesh"); return -3; }
+        if (new_id[hit] != 0xFFFFFFFFu) { set_err(err, err_len, std::string("rr_mesh_reorder_objects: '") + order[k] + "' is listed twice"); return -3; }
+        new_id[hit] = next++;
+    }
+    for (size_t i = 0; i < n; i++) if (new_id[i] == 0xFFFFFFFFu) new_id[i] = next++;      // the unlisted ones keep their relative order behind the listed
+    for (size_t f = 0; f < m->n_faces; f++) {
+        const uint32_t o = m->face_object_id[f];
+        if ((size_t)o >= n) { set_err(err, err_len, "rr_mesh_reorder_objects: face_object_id out of range"); return -3; }
+        m->face_object_id[f] = new_id[o];
+    }
+    std::vector<char*> names(n);
+    for (size_t i = 0; i < n; i++) names[new_id[i]] = m->object_names[i];
+    for (size_t i = 0; i < n; i++) m->object_names[i] = names[i];
+    return 0;
+}
+
 void rr_free_mesh(rr_mesh* m)
 {
     if (!m) return;

@@ -262,8 +262,119 @@ __device__ inline Hit traverse(const float4* __restrict__ base4, const uint32_t 
     return best;
 }
 
+// ---------------------------------------------------------------------------
+// The STACK-FREE walk of the same tree (north_star: "stackless"; RR_STACKLESS=1, round 6 -- measured and not the default, see
+// DESIGN.md §3).  No per-ray memory at all, no LDS: the state is (the node whose four child records the quad's registers hold,
+// the key of the child the walk last went into).  Children are visited in increasing KEY order -- key = (bits(tmin) & ~3) |
+// slot, the key the stack walk ranks by, so the order is the same nearest-first order -- "the next child" being the hit child
+// with the smallest key above the previous one.  Going up follows the parent link in the node's spare word (child record 0's
+// pad: parent offset | slot, written by k_parent_links), and the parent is FETCHED AND TESTED AGAIN: its keys are a pure
+// function of ray and boxes, so the key of the child the walk came back from is recomputed, not remembered -- nothing is kept
+// per level.  Leaves are handled while their node's keys are still in registers.  Culling is exact and late (a child is
+// tested against the cull distance of the moment it is picked).  Price: an internal node is fetched once on the way down and
+// once for every child NODE the walk returns from -- 1.74x the steps of the stack walk on config 3 (tools/treeq.cpp
+// TREEQ_STACKLESS, same hits).  Nearest hit = min over (t, face id) as everywhere: bit-identical results.
+// ---------------------------------------------------------------------------
+__device__ inline Hit traverse_stackless(const float4* __restrict__ base4, const uint32_t tri_base4,
+                                         const RaySetup& R, float range_max, float hit_pad)
+{
+    const int q = threadIdx.x & 3;
+    const V3 o = R.o, d = R.d;
+    const float idx = R.idx, idy = R.idy, idz = R.idz, oox = R.oox, ooy = R.ooy, ooz = R.ooz;
+    unsigned long long bestkey = 0x7F80000000000000ull;
+    uint32_t best_first = 0;
+    float tcull = range_max * 1.0001f + 1e-3f;
+    const uint32_t q2 = 2u * (uint32_t)q, q3 = 3u * (uint32_t)q;
+    uint32_t cur = 0;                    // what this iteration fetches: a node (float4 offset) or a leaf reference
+    int from = -1;                       // >= 0: the node is one the walk RETURNS to, from the child in this slot
+    // the node the walk is in, as this lane sees it: entry / exit distance, key and reference of child q; the node's parent link
+    float tmin = 0.0f, tmax = -1.0f;
+    uint32_t mykey = 0x7FFFFFFFu, myref = 0u, plink = 0xFFFFFFFFu, leafkey = 0u;
+    while (true) {
+        const bool leaf = (cur & kLeafFlag) != 0;
+        const uint32_t first = cur & 0x0FFFFFFFu;
+        const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+        const float4* p = base4 + (first + (leaf ? q3 : q2));
+        const float4 A = p[0], B = p[1];
+        float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (leaf) C = p[2];
+        int prev;
+        if (!leaf) {
+            const float ax = __builtin_fmaf(A.x, idx, oox), bx = __builtin_fmaf(A.w, idx, oox);
+            const float ay = __builtin_fmaf(A.y, idy, ooy), by = __builtin_fmaf(B.x, idy, ooy);
+            const float az = __builtin_fmaf(A.z, idz, ooz), bz = __builtin_fmaf(B.y, idz, ooz);
+            tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            mykey = (__float_as_uint(tmin) & ~3u) | (uint32_t)q;
+            myref = __float_as_uint(B.z);
+            plink = (uint32_t)RR_DPP_I(__float_as_uint(B.w), RR_QBCAST0);
+            // returning: everything up to and including the child the walk came from is done (its key, recomputed)
+            uint32_t pk = (q == from) ? mykey : 0u;
+            pk |= (uint32_t)RR_DPP_I(pk, RR_QXOR1);
+            pk |= (uint32_t)RR_DPP_I(pk, RR_QXOR2);
+            prev = from >= 0 ? (int)pk : -1;
+        } else {
+            // (the leaf step of traverse(): Moeller-Trumbore, grazing guard, quad-wide nearest)
+            const V3 v0 = { A.x, A.y, A.z }, e1 = { B.x, B.y, B.z }, e2 = { C.x, C.y, C.z };
+            const V3 pvec = v_cross(d, e2);
+            const float det = v_dot(e1, pvec);
+            const float inv = 1.0f / det;
+            const V3 tvec = v_sub(o, v0);
+            const float u = v_dot(tvec, pvec) * inv;
+            const V3 qvec = v_cross(tvec, e1);
+            const float v = v_dot(d, qvec) * inv;
+            const float tt = v_dot(e2, qvec) * inv;
+            bool ok = ((uint32_t)q < cnt) && (det != 0.0f) && (u >= 0.0f && u <= 1.0f) && (v >= 0.0f && u + v <= 1.0f) &&
+                      (tt > 0.0f && tt <= range_max);
+            const bool graze = ok && (det * det < C.w);
+            if (__builtin_amdgcn_ballot_w64(graze) != 0ull) {
+                const V3 ph = v_add(o, v_scale(d, tt));
+                const V3 v1 = v_add(v0, e1), v2 = v_add(v0, e2);
+                const bool inside =
+                    ph.x >= fminf(v0.x, fminf(v1.x, v2.x)) - hit_pad && ph.x <= fmaxf(v0.x, fmaxf(v1.x, v2.x)) + hit_pad &&
+                    ph.y >= fminf(v0.y, fminf(v1.y, v2.y)) - hit_pad && ph.y <= fmaxf(v0.y, fmaxf(v1.y, v2.y)) + hit_pad &&
+                    ph.z >= fminf(v0.z, fminf(v1.z, v2.z)) - hit_pad && ph.z <= fmaxf(v0.z, fmaxf(v1.z, v2.z)) + hit_pad;
+                if (graze && !inside) ok = false;
+            }
+            const uint32_t tb = ok ? __float_as_uint(tt) : 0x7F800000u;
+            uint32_t tm = min(tb, (uint32_t)RR_DPP_I(tb, RR_QXOR1));
+            tm = min(tm, (uint32_t)RR_DPP_I(tm, RR_QXOR2));
+            const uint32_t fk = (tb == tm) ? ((__float_as_uint(A.w) << 2) | (uint32_t)q) : 0xFFFFFFFFu;
+            uint32_t fm = min(fk, (uint32_t)RR_DPP_I(fk, RR_QXOR1));
+            fm = min(fm, (uint32_t)RR_DPP_I(fm, RR_QXOR2));
+            const unsigned long long key = ((unsigned long long)tm << 32) | fm;
+            if (key < bestkey) {
+                bestkey = key; best_first = first;
+                tcull = __builtin_fmaf(__uint_as_float(tm), 1.0001f, 1e-3f);
+            }
+            prev = (int)leafkey;
+        }
+        // the next child of the node in registers: the hit child (against the cull distance of NOW) with the smallest key above prev
+        const float lim = __int_as_float(min(__float_as_int(tmax), __float_as_int(tcull)));
+        const bool h = (tmin <= lim) && ((int)mykey > prev);
+        const uint32_t cand = h ? mykey : 0x7FFFFFFFu;
+        uint32_t m = min(cand, (uint32_t)RR_DPP_I(cand, RR_QXOR1));
+        m = min(m, (uint32_t)RR_DPP_I(m, RR_QXOR2));
+        if (m != 0x7FFFFFFFu) {
+            uint32_t nxt = (cand == m) ? myref : 0u;
+            nxt |= (uint32_t)RR_DPP_I(nxt, RR_QXOR1);
+            nxt |= (uint32_t)RR_DPP_I(nxt, RR_QXOR2);
+            cur = nxt; leafkey = m; from = -1;          // (a leaf: the node's registers stay; a node: they are replaced)
+        } else {
+            if (plink == 0xFFFFFFFFu) break;            // the root has no more children: done
+            cur = plink & ~7u; from = (int)(plink & 7u);
+        }
+    }
+    Hit best;
+    best.t = __uint_as_float((uint32_t)(bestkey >> 32));
+    const bool hit = (uint32_t)(bestkey >> 32) < 0x7F800000u;
+    best.face = hit ? ((uint32_t)bestkey >> 2) : 0xFFFFFFFFu;
+    best.tri = hit ? (best_first - tri_base4) / 3u + ((uint32_t)bestkey & 3u) : 0xFFFFFFFFu;
+    return best;
+}
+
 // one 16-ray group (= one wave) of a trace launch: group gx of segment row seg_y (pass 0: tile gx of the flat sequence)
-template <bool FIRST, bool STATS, bool SPILL, bool CULL>
+template <bool FIRST, bool STATS, bool SPILL, bool CULL, bool SL = false>
 __device__ __forceinline__ void trace_group(const Params& P, const int pass, const int seg_y, const int gx, const int count,
                                             uint32_t* lds_stack, const int gdim_x, const PoseArgs* poses = nullptr)
 {
@@ -318,8 +429,10 @@ __device__ __forceinline__ void trace_group(const Params& P, const int pass, con
     unsigned ws[4] = { 0, 0, 0, 0 };
     if (active) {
         const int gray = ((FIRST ? 0 : seg_y) * gdim_x + (int)gx) * kRaysPerBlock + r;   // spill column of this ray slot
-        const Hit h = traverse<STATS, SPILL, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, P.hit_pad, lds_stack, P.stack_lds,
-                                       P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
+        Hit h;
+        if constexpr (SL) h = traverse_stackless(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, P.hit_pad);
+        else h = traverse<STATS, SPILL, CULL>(reinterpret_cast<const float4*>(P.nodes), P.tri_base4, R, P.range_max, P.hit_pad, lds_stack, P.stack_lds,
+                                              P.spill, P.spill_stride, gray, nn, nt, STATS ? ws : nullptr);
         if (q == 0) {
             const size_t hk = (size_t)seg * P.cap + j;
             P.hit[hk] = make_uint2(__float_as_uint((h.tri != 0xFFFFFFFFu) ? h.t : -1.0f), h.tri);
@@ -351,7 +464,7 @@ __device__ __forceinline__ void trace_group(const Params& P, const int pass, con
 }
 
 // grid: (ceil(bound/16) [+ a copy row], n_seg), block 64 (= one wave = 16 rays), dynamic LDS = stack_lds * 16 * (4 | 6) B
-template <bool FIRST, bool STATS, bool SPILL, bool CULL>
+template <bool FIRST, bool STATS, bool SPILL, bool CULL, bool SL = false>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const int pass, const typename PosesOf<FIRST>::type poses)
 {
     // k_trace is the long pole of a step: its waves go first when they share a SIMD with the
@@ -403,7 +516,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(const Params P, const i
     if (!FIRST && gx * kRaysPerBlock >= count) return;
     const PoseArgs* pa = nullptr;
     if constexpr (FIRST) pa = &poses;
-    trace_group<FIRST, STATS, SPILL, CULL>(P, pass, seg_y, gx, count, lds_stack, gdim, pa);
+    trace_group<FIRST, STATS, SPILL, CULL, SL>(P, pass, seg_y, gx, count, lds_stack, gdim, pa);
 }
 
 // The remainder of the segments whose count exceeds the tightened row of this pass (GridHint, rr_device.h): launched
@@ -1410,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t* __restrict__ imgs,
 // with blockIdx % 8 == xcd work keeps the damage to one eighth of the chip.
 // grid `blocks` (8 x blocks when confined), block 64
 // ---------------------------------------------------------------------------
-template <bool NT>
+template <int U>
 __global__ __launch_bounds__(1024) void k_copy_host(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int inflight, int xcd)
 {
     unsigned b = blockIdx.x, nb = gridDim.x;
@@ -1418,27 +1531,31 @@ __global__ __launch_bounds__(1024) void k_copy_host(const uint4* __restrict__ sr
         if ((int)(b & 7u) != xcd) return;
         b >>= 3; nb >>= 3;
     }
+    // U loads of 16 B per lane in flight, then their U stores: the loop is bound by the round trip of a load through a memory
+    // system the frame kernels keep busy (U = 1: 570-670 us per 11 MB beside them where the runtime's blit kernel takes 360)
     const size_t nthreads = (size_t)nb * blockDim.x;
     int k = 0;
-    for (size_t i = (size_t)b * blockDim.x + threadIdx.x; i < n16; i += nthreads) {
-        const uint4 v = src[i];
-        if (NT) {
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 w = { v.x, v.y, v.z, v.w };
-            __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst) + i);
-        } else dst[i] = v;
-        if (inflight > 0 && ++k >= inflight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k = 0; }
+    for (size_t i = (size_t)b * blockDim.x + threadIdx.x; i < n16; i += nthreads * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const size_t e = i + (size_t)u * nthreads; if (e < n16) v[u] = src[e]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const size_t e = i + (size_t)u * nthreads; if (e < n16) dst[e] = v[u]; }
+        if (inflight > 0 && (k += U) >= inflight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k = 0; }
     }
 }
-void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int nt)
+void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int unroll)
 {
     const size_t n16 = bytes / 16;
     if (n16 == 0) return;
     threads = std::max(64, std::min(1024, threads)) & ~63;
     unsigned g = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)blocks, (n16 + threads - 1) / threads));
     if (xcd >= 0) g *= 8u;
-    if (nt) hipLaunchKernelGGL(k_copy_host<true>, dim3(g), dim3(threads), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, inflight, xcd);
-    else hipLaunchKernelGGL(k_copy_host<false>, dim3(g), dim3(threads), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, inflight, xcd);
+    const uint4* a = reinterpret_cast<const uint4*>(src); uint4* d = reinterpret_cast<uint4*>(dst);
+    if (unroll >= 8) hipLaunchKernelGGL(k_copy_host<8>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
+    else if (unroll >= 4) hipLaunchKernelGGL(k_copy_host<4>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
+    else if (unroll >= 2) hipLaunchKernelGGL(k_copy_host<2>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
+    else hipLaunchKernelGGL(k_copy_host<1>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
 }
 
 // what rr_simulate reports beside the image -- the frame's error bits / counters and its per-pass segment statistics -- into
@@ -1492,11 +1609,23 @@ __global__ void k_tri_graze(TriRec* tris, size_t n)
     const V3 c = v_cross(e1, e2);
     tris[i].pad = __float_as_uint(2.5e-5f * v_dot(c, c));
 }
+// ... and every internal node's way up, for the stack-free walk (traverse_stackless): child record 0's spare word of node c =
+// (offset of c's parent) | (c's slot in it); the root keeps 0xFFFFFFFF.  Runs behind k_encode_refs (references are offsets by then)
+__global__ void k_parent_links(Node4* nodes, size_t n_children)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) nodes[0].c[0].pad = 0xFFFFFFFFu;
+    if (i >= n_children) return;
+    const uint32_t r = nodes[i >> 2].c[i & 3].ref;
+    if (r == kEmptyRef || (r & kLeafFlag)) return;
+    nodes[r >> 3].c[0].pad = (uint32_t)((i >> 2) << 3) | (uint32_t)(i & 3);
+}
 void launch_encode_refs(Node4* nodes, size_t n_nodes, uint32_t tri_base4, hipStream_t s, size_t n_tris)
 {
     const size_t n = n_nodes * 4;
     if (n == 0) return;
     hipLaunchKernelGGL(k_encode_refs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nodes, n, tri_base4);
+    hipLaunchKernelGGL(k_parent_links, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nodes, n);
     if (n_tris) hipLaunchKernelGGL(k_tri_graze, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<TriRec*>(reinterpret_cast<float4*>(nodes) + tri_base4), n_tris);
 }
@@ -1541,7 +1670,10 @@ void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, 
     // rocprofv3 reports), not the time the launch spent waiting for CUs held by other streams
 #define RR_LAUNCH_TRACE0(S, X) hipExtLaunchKernelGGL((k_trace<true, S, X, false>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass, *poses)
 #define RR_LAUNCH_TRACE(F, S, X, C) hipExtLaunchKernelGGL((k_trace<F, S, X, C>), grid, block, lds, s, ev_start, ev_stop, 0, Pl, pass, NoPoses{})
-    if (pass == 0) {
+    if (P.stackless && !stats) {       // the stack-free walk: no LDS at all (RR_STACKLESS=1; the statistics build keeps the stack walk)
+        if (pass == 0) hipExtLaunchKernelGGL((k_trace<true, false, false, false, true>), grid, block, 0, s, ev_start, ev_stop, 0, Pl, pass, *poses);
+        else hipExtLaunchKernelGGL((k_trace<false, false, false, false, true>), grid, block, 0, s, ev_start, ev_stop, 0, Pl, pass, NoPoses{});
+    } else if (pass == 0) {
         if (stats) { if (spill) RR_LAUNCH_TRACE0(true, true); else RR_LAUNCH_TRACE0(true, false); }
         else       { if (spill) RR_LAUNCH_TRACE0(false, true); else RR_LAUNCH_TRACE0(false, false); }
     } else if (cull) {
@@ -1567,7 +1699,11 @@ void launch_trace(const Params& P, int pass, const PoseArgs* poses, bool stats, 
 
 // the pass-0 trace kernel of the plain build (no statistics): the node of a replayed launch graph whose parameters change from
 // replay to replay -- (Params, pass, PoseArgs) -- see rr_api.hip: run_frame
-void* trace0_kernel(bool spill) { return spill ? (void*)k_trace<true, false, true, false> : (void*)k_trace<true, false, false, false>; }
+void* trace0_kernel(bool spill, bool stackless)
+{
+    if (stackless) return (void*)k_trace<true, false, false, false, true>;
+    return spill ? (void*)k_trace<true, false, true, false> : (void*)k_trace<true, false, false, false>;
+}
 // ... and the Params bytes launch_trace hands that kernel
 Params trace0_params(const Params& P) { Params Pl = P; Pl.copy_blocks = 0; return Pl; }
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "rr_multi_set_mesh", "rr_multi_set_mesh_gpu", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
     "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
     "rr_multi_simulate_batch_async", "rr_multi_wait", "rr_peek_error_bits_async", "rr_get_traversal_shape",
-    "rr_cone_dirs", "rr_sample_cone_local", "rr_load_mesh_file", "rr_free_mesh",
+    "rr_cone_dirs", "rr_sample_cone_local", "rr_load_mesh_file", "rr_mesh_reorder_objects", "rr_free_mesh",
     "rr_simulate_param_sets_device", "rr_simulate_param_sets", "rr_score_images_device",
 ]
 
@@ -182,6 +182,7 @@ def lib():
     L.rr_sample_cone_local.argtypes = [C.c_uint32, C.c_float, C.c_size_t, C.c_int, C.c_float, vp]
     L.rr_load_mesh_file.argtypes = [C.c_char_p, C.POINTER(RRMesh), C.c_char_p, C.c_size_t]
     L.rr_free_mesh.argtypes = [C.POINTER(RRMesh)]
+    L.rr_mesh_reorder_objects.argtypes = [C.POINTER(RRMesh), C.POINTER(C.c_char_p), C.c_size_t, C.c_char_p, C.c_size_t]
     L.rr_free_mesh.restype = None
     for n in SYMBOLS:
         getattr(L, n)
@@ -557,14 +558,21 @@ def sample_cone_local(seed, width_rad, n, sample_dist=2, p_in_cone=0.8):
     return out
 
 
-def load_mesh_file(path):
-    """rr_load_mesh_file (host only): PLY / OBJ / DAE -> {"verts", "faces", "face_object_id", "n_objects", "object_names"}."""
+def load_mesh_file(path, object_order=None):
+    """rr_load_mesh_file (host only): PLY / OBJ / DAE -> {"verts", "faces", "face_object_id", "n_objects", "object_names"}.
+    object_order: names in the order their ids should run (rr_mesh_reorder_objects: the file's own numbering is depth-first
+    scene order -- a material list written for another numbering, e.g. rmagine's, is matched by naming the objects)."""
     m = RRMesh()
     err = C.create_string_buffer(512)
     rc = lib().rr_load_mesh_file(str(path).encode(), C.byref(m), err, len(err))
     if rc:
         raise RRError("%s (rc=%d)" % (err.value.decode(errors="replace"), rc))
     try:
+        if object_order:
+            names = (C.c_char_p * len(object_order))(*[str(x).encode() for x in object_order])
+            rc = lib().rr_mesh_reorder_objects(C.byref(m), names, len(object_order), err, len(err))
+            if rc:
+                raise RRError("%s (rc=%d)" % (err.value.decode(errors="replace"), rc))
         out = {"verts": np.ctypeslib.as_array(m.verts, (m.n_verts, 3)).copy() if m.n_verts else np.zeros((0, 3), np.float32),
                "faces": np.ctypeslib.as_array(m.faces, (m.n_faces, 3)).copy() if m.n_faces else np.zeros((0, 3), np.uint32),
                "face_object_id": np.ctypeslib.as_array(m.face_object_id, (m.n_faces,)).copy() if m.n_faces else np.zeros(0, np.uint32),

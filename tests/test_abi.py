@@ -207,3 +207,31 @@ def test_bench_refuses_more_gpus_than_the_box_has_at_once():
     assert "--gpus 64 asked for" in r.stderr and "not launched" in r.stderr
     assert r.stdout.strip() == ""
     assert time.time() - t0 < 60
+
+
+def test_hand_declared_rccl_abi_matches_rccl_h():
+    """csrc/rr_multi.hip loads librccl at run time and calls it through prototypes declared BY HAND: the
+    parameter lists and the datatype constant are compared with the image's rccl.h here, so that a drift shows on the CPU and
+    not inside the first 8-GPU run.  (At run time rr_create_multi also refuses a library outside NCCL [2.7, 3.0) and sends 16
+    guarded bytes through the constant it takes for ncclUint8.)"""
+    import re
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl.h in this image")
+    h = open(hdr).read()
+    src = open(os.path.join(ROOT, "radarays_ros_amd", "csrc", "rr_multi.hip")).read()
+    assert re.search(r"ncclUint8\s*=\s*1\b", h) and re.search(r"kNcclUint8\s*=\s*1\b", src)
+    major, minor = int(re.search(r"#define NCCL_MAJOR (\d+)", h).group(1)), int(re.search(r"#define NCCL_MINOR (\d+)", h).group(1))
+    assert major == 2 and minor >= 7                                  # the range rr_create_multi accepts
+    norm = lambda s: re.sub(r"\s+", "", re.sub(r"\b(sendbuff|recvbuff|count|datatype|peer|comm|stream|ndev|devlist|result|version)\b", "", s))   # noqa: E731
+    want = {"CommInitAll": "(ncclComm_t*, int, const int*)", "CommDestroy": "(ncclComm_t)",
+            "Send": "(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)",
+            "Recv": "(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)",
+            "GroupStart": "()", "GroupEnd": "()", "GetErrorString": "(ncclResult_t)", "GetVersion": "(int*)"}
+    for name, params in want.items():
+        m = re.search(r"\bnccl%s\s*\(([^)]*)\)\s*;" % name, h)
+        assert m, name
+        assert norm("(" + m.group(1) + ")") == norm(params), (name, m.group(1))
+        d = re.search(r"\(\*%s\)\s*\(([^)]*)\)" % name, src)                       # the hand-written declaration
+        assert d and norm("(" + d.group(1) + ")") == norm(params), (name, d and d.group(1))
+    assert re.search(r"const char\*\s*ncclGetErrorString", h) and re.search(r"const char\* \(\*GetErrorString\)", src)

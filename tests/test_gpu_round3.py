@@ -65,15 +65,18 @@ def test_multi_with_one_device_equals_rr_simulate(native_lib, small):
         native_lib.MultiContext([0, 977])
 
 
-@pytest.mark.parametrize("fold_always", [False, True])
-def test_batch_host_async_delivers_the_same_images(native_lib, small, fold_always, monkeypatch):
+@pytest.mark.parametrize("route", ["sdma", "deferred", "deferred_fold_always"])
+def test_batch_host_async_delivers_the_same_images(native_lib, small, route, monkeypatch):
     """Images delivered to page-locked host memory, several batches in flight on two streams: every image equals
-    rr_simulate's; rr_wait_host(ptr) completes exactly that buffer.  A batch's images either leave with a plain copy or
-    wait on their lane and ride out on the trace launches of the lane's next batch (a few waves, one store in flight
-    each); the library picks by how many other batches are in flight -- `fold_always` forces the second way wherever it is
-    possible, so both are checked byte for byte."""
+    rr_simulate's; rr_wait_host(ptr) completes exactly that buffer.  Routes: `sdma` (the default since round 6: each batch's
+    images leave at once over the SDMA engines through ROCr, csrc/rr_sdma.cpp) and the fallback (RR_HOST_SDMA=0), where a
+    batch's images either leave with a plain copy or wait on their lane and ride out on the trace launches of the lane's next
+    batch (a few waves, one store in flight each) -- the library picks by how many other batches are in flight,
+    `deferred_fold_always` forces the second way wherever it is possible.  All checked byte for byte."""
     import torch
     s, cfg, mats, beams, noise, poses = small
+    monkeypatch.setenv("RR_HOST_SDMA", "1" if route == "sdma" else "0")
+    fold_always = route == "deferred_fold_always"
     if fold_always:
         monkeypatch.setenv("RR_FOLD_MIN_BUSY", "0")
     c = native_lib.Context(0)

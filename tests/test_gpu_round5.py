@@ -99,6 +99,11 @@ def test_include_motion_through_the_batch_path(native_lib, motion_case):
     for f in range(len(sweeps)):
         assert np.array_equal(h.array[f], one_by_one[f]), f
     h.close()
+    # ONE table and a batch of several frames: refused (every frame would be the same sweep, the call's poses ignored)
+    c.set_motion_poses(sweeps[0])
+    with pytest.raises(native_lib.RRError, match="ONE per-azimuth pose table"):
+        c.simulate_batch_device(sweeps[:2, 0], imgs.data_ptr(), st)
+    c.simulate_batch_device(sweeps[:1, 0], imgs.data_ptr(), st); c.synchronize(st)      # one frame: what the table is for
     # a table count that is not a multiple of n_angles is refused; switching off gives static frames again
     with pytest.raises(native_lib.RRError):
         c.set_motion_poses(sweeps[0][:399]); c.simulate(sweeps[0][0])

@@ -74,6 +74,46 @@ def test_rr_load_mesh_file_polygons_big_endian_and_obj(tmp_path):
         assert np.array_equal(c[k], py[k]), k
 
 
+def test_object_order_permutes_the_object_ids_and_nothing_else(tmp_path):
+    """The material list of a scene is indexed by object id (m_object_materials[obj_id], RadarCPU.cpp:268;
+    config/oru4_test.yaml:37-56); this build numbers objects in depth-first scene order, rmagine's importer may not
+    (radar_simulator.cpp:149).  rr_mesh_reorder_objects / the adapter's ~hip_object_order renumber by NAME: only
+    face_object_id and the order of the names change."""
+    o = tmp_path / "scene.obj"
+    o.write_text("o ground\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n"
+                 "o wall\nv 0 0 1\nv 1 0 1\nv 1 1 1\nf 5 6 7\n"
+                 "o roof\nv 0 0 2\nv 1 0 2\nv 1 1 2\nf 8 9 10\nf 10 9 8\n"
+                 "o pole\nv 0 0 3\nv 1 0 3\nv 1 1 3\nf 11 12 13\n")
+    base = native.load_mesh_file(o)
+    assert base["object_names"] == ["ground", "wall", "roof", "pole"] and base["face_object_id"].tolist() == [0, 0, 1, 2, 2, 3]
+    for order in (["roof", "ground", "pole", "wall"], ["pole"], ["wall", "ground"], []):
+        m = native.load_mesh_file(o, object_order=order)
+        assert np.array_equal(m["verts"], base["verts"]) and np.array_equal(m["faces"], base["faces"]) and m["n_objects"] == 4
+        want_names = list(order) + [n for n in base["object_names"] if n not in order]      # unlisted: relative order kept, behind the listed
+        assert m["object_names"] == want_names
+        new_id = {n: k for k, n in enumerate(want_names)}
+        assert m["face_object_id"].tolist() == [new_id[base["object_names"][i]] for i in base["face_object_id"]]
+    # a material list written for ANOTHER numbering gives the same per-face materials once the objects are named in its order
+    mats_theirs = {"roof": 3, "ground": 1, "pole": 4, "wall": 2}
+    theirs = native.load_mesh_file(o, object_order=["roof", "ground", "pole", "wall"])
+    per_face_theirs = [[3, 1, 4, 2][i] for i in theirs["face_object_id"]]
+    per_face_ours = [[mats_theirs[n] for n in base["object_names"]][i] for i in base["face_object_id"]]
+    assert per_face_theirs == per_face_ours
+    for bad, msg in ((["ground", "nope"], "no object named 'nope'"), (["wall", "wall"], "listed twice")):
+        with pytest.raises(native.RRError, match=msg):
+            native.load_mesh_file(o, object_order=bad)
+    dup = tmp_path / "dup.obj"
+    dup.write_text("o a\nv 0 0 0\nv 1 0 0\nv 1 1 0\nf 1 2 3\no a\nv 0 0 1\nv 1 0 1\nv 1 1 1\nf 4 5 6\n")
+    if native.load_mesh_file(dup)["object_names"].count("a") == 2:
+        with pytest.raises(native.RRError, match="two objects named"):
+            native.load_mesh_file(dup, object_order=["a"])
+    ply = tmp_path / "t.ply"
+    ply.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                   "property list uchar int vertex_index\nend_header\n0 0 0\n1 0 0\n1 1 0\n3 0 1 2\n")
+    with pytest.raises(native.RRError, match="no object names"):
+        native.load_mesh_file(ply, object_order=["x"])
+
+
 def test_rr_load_mesh_file_errors(tmp_path):
     p = tmp_path / "x.ply"
     p.write_text("nope\n")

@@ -5,7 +5,8 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 pick() { grep -o "\"value\": [0-9.]*" | head -1 | tr '\n' ' '; }
 run() { local label=$1; shift; local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   echo "$label: $(env "${envs[@]}" timeout 300 python "$@" 2> gpurun_out/r6_exp3_err.log | pick)" >> $O; }
-timeout 600 python -m pytest tests/test_gpu_round6.py -x -q -m gpu > gpurun_out/r6_exp3_pytest.log 2>&1; echo "pytest r6 rc=$? $(tail -1 gpurun_out/r6_exp3_pytest.log)" >> $O
+timeout 600 python -m pytest tests/test_gpu_round6.py -x -q -m gpu -s > gpurun_out/r6_exp3_pytest.log 2>&1; echo "pytest r6 rc=$? $(tail -1 gpurun_out/r6_exp3_pytest.log)" >> $O
+grep "fresnel GPU vs oracle" gpurun_out/r6_exp3_pytest.log >> $O
 C2="--workload config2_100k_400x200_1pass --no-cpu-baseline --no-extras --steps 100 --warmup 5"
 export RR_BENCH_LIVE_TIMING=0
 run "c2 memcpy" RR_FLUSH_KERNEL=0 -- bench.py $C2

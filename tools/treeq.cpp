@@ -7,6 +7,8 @@
 //   python tools/treeq_dump.py <config id> <passes> <out dir>     (scene + rays: the oracle's ORC_RAYLOG)
 //   g++ -O2 -std=c++17 -ffp-contract=off -I radarays_ros_amd/csrc tools/treeq.cpp radarays_ros_amd/csrc/rr_bvh.cpp -o /tmp/treeq -lpthread
 //   RR_BVH_ALPHA=1e-5 RR_BVH_BUDGET=1 /tmp/treeq <out dir>
+//   TREEQ_STACKLESS=1: the stack-free walk north_star names (round 6) -- parent links, children visited in key order, a node
+//   re-fetched and re-tested every time the walk returns to it; prints its fetch counts beside the stack walk's.
 //   TREEQ_CULL_POP=1: with the later passes' cull at pop time; TREEQ_PREDICT / TREEQ_SORTED: ray-order studies; TREEQ_SLAB: an extra
 //   pair of planes per child (all of them studies whose results are in DESIGN_EXPERIMENTS.md)
 #include "rr_bvh.h"
@@ -131,6 +133,78 @@ static Cost trace(const Bvh4& B, const float o[3], const float d[3], float range
     return c;
 }
 
+// The stack-free walk (north_star: "stackless"; round 6 study).  No per-ray memory at all: the state is (node, key of the
+// child the walk came back from).  Children of a node are visited in increasing KEY order -- key = (bits(tmin) & ~3) | slot,
+// the very key the stack walk sorts by, so the visiting order is the same nearest-first order -- and "the next child" is the
+// hit child with the smallest key above the previous one; that previous key is recomputed from the node's own boxes when the
+// walk returns (the slab test is a pure function of ray and box), so nothing has to be remembered per level.  Going up takes
+// the parent link in the node's spare word, and the parent is fetched and tested AGAIN: an internal node costs one fetch on
+// the way down and one for every child NODE the walk returns from (leaves are handled while the node's four keys are still in
+// registers).  Culling is exact and late: a child is tested against the cull distance of the moment it is picked.
+static Cost trace_stackless(const Bvh4& B, const std::vector<uint32_t>& parent, const float o[3], const float d[3], float range_max)
+{
+    Cost c;
+    float inv[3], oo[3];
+    for (int k = 0; k < 3; k++) {
+        float dk = d[k];
+        if (std::fabs(dk) < 1e-20f) dk = std::copysign(1e-20f, dk);
+        inv[k] = 1.0f / dk; oo[k] = -o[k] * inv[k];
+    }
+    float best_t = INFINITY; uint32_t best_face = 0xFFFFFFFFu;
+    float tcull = range_max * 1.0001f + 1e-3f;
+    uint32_t node = 0; int from_slot = -1;
+    while (true) {
+        c.nodes++;                                   // a fetch of the node's four child records (first visit or return)
+        if (from_slot >= 0) c.merged++;              // (re-used counter: RE-fetches)
+        const Node4& n = B.nodes[node];
+        float tn[4], tf[4]; uint32_t key[4];
+        for (int q = 0; q < 4; q++) {
+            const Child4& ch = n.c[q];
+            tn[q] = 0.f; tf[q] = INFINITY;
+            for (int k = 0; k < 3; k++) {
+                const float a = std::fma(ch.lo[k], inv[k], oo[k]), b = std::fma(ch.hi[k], inv[k], oo[k]);
+                tn[q] = std::max(tn[q], std::min(a, b)); tf[q] = std::min(tf[q], std::max(a, b));
+            }
+            uint32_t bits; memcpy(&bits, &tn[q], 4);
+            key[q] = (bits & ~3u) | (uint32_t)q;
+        }
+        long prev = from_slot >= 0 ? (long)key[from_slot] : -1;
+        bool descended = false;
+        while (true) {
+            int pick = -1;
+            for (int q = 0; q < 4; q++)
+                if (n.c[q].ref != kEmptyRef && tn[q] <= std::min(tf[q], tcull) && (long)key[q] > prev && (pick < 0 || key[q] < key[pick])) pick = q;
+            if (pick < 0) break;
+            prev = (long)key[pick];
+            const uint32_t ref = n.c[pick].ref;
+            if (!(ref & kLeafFlag)) { node = ref; from_slot = -1; descended = true; break; }
+            c.leaves++;
+            const uint32_t first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++) {
+                c.tris++;
+                const TriRec& T = B.tris[first + i];
+                const float* v0 = T.v0; const float* e1 = T.e1; const float* e2 = T.e2;
+                const float pv[3] = { d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0] };
+                const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+                const float invd = 1.0f / det;
+                const float tv[3] = { o[0] - v0[0], o[1] - v0[1], o[2] - v0[2] };
+                const float u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * invd;
+                const float qv[3] = { tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0] };
+                const float v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * invd;
+                const float tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * invd;
+                const bool ok = det != 0.0f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && tt > 0.0f && tt <= range_max;
+                if (ok && (tt < best_t || (tt == best_t && T.face < best_face))) { best_t = tt; best_face = T.face; tcull = std::fma(tt, 1.0001f, 1e-3f); }
+            }
+        }
+        if (descended) continue;
+        if (node == 0) break;
+        const uint32_t pl = parent[node];
+        node = pl >> 2; from_slot = (int)(pl & 3u);
+    }
+    if (best_face != 0xFFFFFFFFu) { c.t = best_t; c.face = best_face; }
+    return c;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: treeq <dir with verts.f32 faces.u32 rays.bin> [threads]\n"); return 2; }
@@ -215,6 +289,36 @@ int main(int argc, char** argv)
     std::vector<Cost> cost(rays.size());
 #pragma omp parallel for schedule(dynamic, 256)
     for (long i = 0; i < (long)rays.size(); i++) cost[i] = trace(B, rays[i].o, rays[i].d, 1000.0f);
+    if (getenv("TREEQ_STACKLESS")) {
+        std::vector<uint32_t> parent(B.nodes.size(), 0xFFFFFFFFu);
+        for (size_t ni = 0; ni < B.nodes.size(); ni++) for (int q = 0; q < 4; q++) {
+            const uint32_t r = B.nodes[ni].c[q].ref;
+            if (r != kEmptyRef && !(r & kLeafFlag)) parent[r] = (uint32_t)(ni << 2) | (uint32_t)q;
+        }
+        std::vector<Cost> sl(rays.size());
+#pragma omp parallel for schedule(dynamic, 256)
+        for (long i = 0; i < (long)rays.size(); i++) sl[i] = trace_stackless(B, parent, rays[i].o, rays[i].d, 1000.0f);
+        size_t bad = 0; double n = 0, l = 0, t = 0, re = 0, n0 = 0, l0 = 0;
+        for (size_t i = 0; i < rays.size(); i++) {
+            if (sl[i].face != cost[i].face || sl[i].t != cost[i].t) bad++;
+            n += sl[i].nodes; l += sl[i].leaves; t += sl[i].tris; re += sl[i].merged; n0 += cost[i].nodes; l0 += cost[i].leaves;
+        }
+        const double m = (double)rays.size();
+        // wave estimate as below: 16 consecutive rays of one (azimuth, pass)
+        double ws = 0, ws0 = 0; size_t nw = 0;
+        for (size_t k = 0; k < rays.size(); ) {
+            size_t e = k; unsigned mx = 0, mx0 = 0;
+            for (; e < std::min(rays.size(), k + 16) && rays[e].az == rays[k].az && rays[e].pass == rays[k].pass; e++) {
+                mx = std::max(mx, sl[e].nodes + sl[e].leaves); mx0 = std::max(mx0, cost[e].nodes + cost[e].leaves);
+            }
+            ws += mx; ws0 += mx0; nw++; k = e;
+        }
+        printf("stackless: hits equal to the stack walk's: %s (%zu differ)\n", bad ? "NO" : "yes", bad);
+        printf("stackless: node fetches/ray %.2f (%.2f of them re-fetches on the way up; stack walk %.2f)  leaves/ray %.2f (stack %.2f)  tris/ray %.2f\n",
+               n / m, re / m, n0 / m, l / m, l0 / m, t / m);
+        printf("stackless: steps/ray %.2f vs %.2f (x%.2f)  wave iterations (est.) %.2f vs %.2f (x%.2f)  bytes/ray %.1f\n",
+               (n + l) / m, (n0 + l0) / m, (n + l) / (n0 + l0), ws / nw, ws0 / nw, ws / ws0, (n * 128 + t * 48) / m + 132);
+    }
 
     if (getenv("TREEQ_TWO_LEVEL")) {
         // experiment: faces much larger than the median in their own tree, the rest in another; a ray walks the
