@@ -207,7 +207,7 @@ int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint
  * h_imgs_u8) (NULL: every outstanding buffer) or rr_synchronize() -- until then the buffer must stay valid and must not be
  * read.  How the bytes travel is the library's business.  By default they leave at once over the SDMA engines, submitted
  * through ROCr by a worker thread of the context behind the batch's last kernel (csrc/rr_sdma.cpp): no shader core stores a byte
- * of them, and it is the same engine whichever HIP runtime serves the process (the runtime inside the PyTorch wheel would
+ * of them, and it is the same engine whichever HIP runtime serves the process (a ROCm 7.0.2 runtime, e.g. the one a Python ML wheel bundles, would
  * carry a hipMemcpyAsync as a blit kernel: 27-35k images/s on config 2 where SDMA delivers the link's 39k).  Where that path
  * is not available (RR_HOST_SDMA=0, a pageable buffer, no reachable ROCr) a batch's images wait in device memory and ride out on the
  * trace launches of the next batch that uses the same frame lane (a few waves trickle them over PCIe with one store in
@@ -234,6 +234,12 @@ void  rr_host_free(void* p);
  * loop's flush_host) takes this route, so the delivered rate does not depend on it.  Replaces nothing in the reference
  * (cv_bridge deep-copies m_polar_image on the host, RadarCPU.cpp:555-558). */
 int rr_copy_to_host_async(rr_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
+/* The same for a caller that can fence with rr_wait_host instead of the stream: bytes of a caller-owned device buffer leave
+ * over the SDMA engines (the route of rr_simulate_batch_host_async, csrc/rr_sdma.cpp) once the work enqueued on `stream` so
+ * far has completed.  Returns at once; h_dst is complete -- and d_src may be overwritten -- after rr_wait_host(ctx, h_dst)
+ * (NULL: everything outstanding) or rr_synchronize().  Where the SDMA path is not available it is rr_copy_to_host_async plus
+ * an event.  rr_multi's root and the sharded step loop's flush deliver this way. */
+int rr_deliver_to_host_async(rr_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
 
 /* Assemble the mono8 image from column-major columns, applying scroll_image
  * (RadarCPU.cpp:457): d_img[c][(scroll + a) % n_angles] = d_cols[a][c].
@@ -493,9 +499,9 @@ void rr_free_mesh(rr_mesh* m);
  * RR_HOST_COPY_STREAM (0) 1: one-pass frames (nothing later could carry their images) are copied out at once on one dedicated stream
  * RR_FLUSH_KERNEL (1)     a host copy that does not ride on a trace launch (one-pass frames, the end of a run, rr_copy_to_host_async)
  *                         is stored by the library's own kernel when the destination is page-locked; 0: hipMemcpyAsync
- * RR_FLUSH_BLOCKS (32)    ... its one-wave workgroups
- * RR_FLUSH_INFLIGHT (4)   ... 1-KB stores a wave keeps outstanding (0: no limit)
- * RR_FLUSH_THREADS (64)   ... threads per workgroup (64..1024); RR_FLUSH_UNROLL (1): 16-byte loads a lane keeps in flight (1, 2, 4, 8)
+ * RR_FLUSH_BLOCKS (8)     ... its workgroups
+ * RR_FLUSH_INFLIGHT (0)   ... 1-KB stores a wave keeps outstanding (0: no limit)
+ * RR_FLUSH_THREADS (256)  ... threads per workgroup (64..1024)
  * RR_FLUSH_XCD (0)        ... the XCD all of them run on (PCIe-paced stores then fill the write queues of one XCD only); -1: all eight
  * RR_FOLD_MIN_BUSY (2)    other lanes that must be busy for a host copy to be folded into the next batch
  * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)

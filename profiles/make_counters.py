@@ -3,7 +3,7 @@
 the launch durations it measures live:
   SQ_INSTS_VALU   wave-level VALU instructions per launch of each kernel (the VALU-issue roofline)
   hbm_bytes       2 x FETCH_SIZE + WRITE_SIZE (KB -> B) per launch: HBM traffic (secondary view)
-The k_trace variants are <FIRST, STATS, SPILL, CULL>: "trace0" = <true, false, *, *> (pass 0), "trace" = <false, false, *, *>
+The k_trace variants are <FIRST, STATS, SPILL, CULL, STACKLESS> (the fifth since round 6; false unless RR_STACKLESS=1): "trace0" = <true, false, *, *> (pass 0), "trace" = <false, false, *, *>
 (passes 1..P-1, launch-weighted mean); the counting builds (<*, true, *, *>) are instrumentation and left out.
 usage: profiles/make_counters.py <round tag> [workload=suffix ...]   e.g.  make_counters.py r03 target_10M_400x200_4pass= config3_1M_400x200_4pass=_c3"""
 import json, os, sys

@@ -37,7 +37,7 @@ void launch_mat_limits(const float4* materials, size_t n, double* limits, hipStr
 void* trace0_kernel(bool spill, bool stackless);
 Params trace0_params(const Params& P);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
-void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int unroll);
+void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads);
 void launch_frame_report(const Counters* cnt, const SegStats* ss, size_t n_ss, void* h_dst, hipStream_t s);
 void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s);
 void launch_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
@@ -216,8 +216,8 @@ struct rr_ctx {
     // with a single batch in flight) is stored by the library's own kernel (k_copy_host) when the destination is page-locked:
     // flush_blocks one-wave workgroups with at most flush_inflight 1-KB stores outstanding each (RR_FLUSH_BLOCKS, RR_FLUSH_INFLIGHT;
     // RR_FLUSH_KERNEL=0: hipMemcpyAsync, i.e. whichever engine the process' HIP runtime picks)
-    int flush_kernel = 1, flush_blocks = 32, flush_inflight = 4;
-    int flush_threads = 64, flush_unroll = 1;  // threads per workgroup of the copy kernel (RR_FLUSH_THREADS), 16-byte loads per lane in flight (RR_FLUSH_UNROLL)
+    int flush_kernel = 1, flush_blocks = 8, flush_inflight = 0;
+    int flush_threads = 256;     // threads per workgroup of the copy kernel (RR_FLUSH_THREADS)
     int flush_xcd = 0;           // the copy kernel's workgroups all on this XCD (RR_FLUSH_XCD 0..7; -1: dealt out over all eight)
     // RR_HOST_COPY_STREAM=1 (experiment, round 6): a batch that cannot fold its predecessor's images into a trace launch (one-pass
     // frames) sends its OWN images at once on one dedicated copy stream -- copies then run one at a time, in order, beside the
@@ -227,6 +227,11 @@ struct rr_ctx {
     // copies in order, each behind its batch's last kernel) instead of a copy the HIP runtime would pick an engine for; 0, a
     // pageable destination or a runtime ROCr cannot be reached through: the deferred / trickled copies below
     int host_sdma = 1; SdmaCopier* sdma = nullptr; bool sdma_tried = false;
+    // rr_deliver_to_host_async: copies of caller-owned device buffers that rr_wait_host fences (an SDMA job, or -- fallback -- an
+    // event behind a stream-ordered copy); events are pooled
+    struct Delivery { const void* dst; uint64_t job; hipEvent_t ev; };
+    std::vector<Delivery> deliveries;
+    std::vector<hipEvent_t> delivery_events;
     int copy_blocks = 8;         // workgroups (one wave each) of a later-pass trace launch that trickle a folded host copy (RR_COPY_BLOCKS; 0: never fold)
     int tight_grid = 1;          // later-pass trace rows sized by what earlier batches needed (RR_TIGHT_GRID=0: the doubling bound)
     int tight_force = 0;         // RR_TIGHT_FORCE=n: rows of n workgroups whatever the history says (tests of the repair path)
@@ -614,7 +619,7 @@ int copy_out(rr_ctx* c, const void* d_src, void* h_dst, size_t bytes, bool visib
 {
     if (bytes == 0) return 0;
     if (c->flush_kernel && visible && bytes % 16 == 0 && ((uintptr_t)h_dst | (uintptr_t)d_src) % 16 == 0) {
-        launch_copy_host(d_src, h_dst, bytes, c->flush_blocks, c->flush_inflight, c->flush_xcd, s, c->flush_threads, c->flush_unroll);
+        launch_copy_host(d_src, h_dst, bytes, c->flush_blocks, c->flush_inflight, c->flush_xcd, s, c->flush_threads);
         RR_HIP(c, hipGetLastError());
     } else RR_HIP(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
     return 0;
@@ -968,7 +973,6 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_FLUSH_INFLIGHT")) c->flush_inflight = std::max(0, std::min(64, atoi(getenv("RR_FLUSH_INFLIGHT"))));
     if (getenv("RR_FLUSH_XCD")) c->flush_xcd = std::max(-1, std::min(7, atoi(getenv("RR_FLUSH_XCD"))));
     if (getenv("RR_FLUSH_THREADS")) c->flush_threads = std::max(64, std::min(1024, atoi(getenv("RR_FLUSH_THREADS"))));
-    if (getenv("RR_FLUSH_UNROLL")) c->flush_unroll = std::max(1, std::min(8, atoi(getenv("RR_FLUSH_UNROLL"))));
     if (getenv("RR_TIGHT_GRID")) c->tight_grid = atoi(getenv("RR_TIGHT_GRID")) != 0;
     if (getenv("RR_TIGHT_FORCE")) c->tight_force = std::max(0, atoi(getenv("RR_TIGHT_FORCE")));
     {   // the one angle of total reflection that does not depend on the material table
@@ -999,6 +1003,8 @@ void rr_destroy(rr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();   // frames may still be in flight on the lanes' or the caller's streams
     if (c->sdma) { sdma_destroy(c->sdma); c->sdma = nullptr; }      // (its queued copies wait for events that have completed by now)
+    for (rr_ctx::Delivery& d : c->deliveries) (void)hipEventDestroy(d.ev);
+    for (hipEvent_t e : c->delivery_events) (void)hipEventDestroy(e);
     for (auto& kv : c->timers) for (auto& p : kv.second.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->d_bvh.release(); c->d_qas.release(); c->d_beams.release(); c->d_materials.release(); c->d_mat_limits.release();
@@ -1415,6 +1421,51 @@ void* rr_host_alloc(size_t bytes)
 
 void rr_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+namespace {
+// the SDMA worker of the context, made on first use (nullptr: not available / switched off)
+SdmaCopier* sdma_of(rr_ctx* c, const void* any_device_ptr)
+{
+    if (!c->host_sdma) return nullptr;
+    if (!c->sdma && !c->sdma_tried) {
+        c->sdma_tried = true;
+        std::string why;
+        c->sdma = sdma_create(c->device, any_device_ptr, why);
+        if (!c->sdma && getenv("RR_HOST_SDMA_VERBOSE")) fprintf(stderr, "[rr] SDMA delivery not available: %s\n", why.c_str());
+    }
+    if (c->sdma && sdma_failed(c->sdma, nullptr)) {
+        if (getenv("RR_HOST_SDMA_VERBOSE")) { std::string why; (void)sdma_failed(c->sdma, &why); fprintf(stderr, "[rr] SDMA delivery switched off: %s\n", why.c_str()); }
+        c->host_sdma = 0;
+        return nullptr;
+    }
+    return c->sdma;
+}
+}  // namespace
+
+int rr_deliver_to_host_async(rr_ctx* c, const void* d_src, void* h_dst, size_t bytes, void* stream)
+{
+    if (!c) return -1;
+    if (bytes == 0) return 0;
+    if (!d_src || !h_dst) return fail(c, -3, "rr_deliver_to_host_async: null pointer");
+    RR_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipEvent_t ev = nullptr;
+    if (!c->delivery_events.empty()) { ev = c->delivery_events.back(); c->delivery_events.pop_back(); }
+    else RR_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const bool visible = host_visible(h_dst);
+    SdmaCopier* sd = visible ? sdma_of(c, d_src) : nullptr;
+    uint64_t job = 0;
+    if (sd) {
+        RR_HIP(c, hipEventRecord(ev, s));                  // the copy starts once the stream has got here
+        job = sdma_submit(sd, ev, d_src, h_dst, bytes);
+    } else {
+        const int rc = copy_out(c, d_src, h_dst, bytes, visible, s);
+        if (rc) { c->delivery_events.push_back(ev); return rc; }
+        RR_HIP(c, hipEventRecord(ev, s));                  // ... is complete once the stream has got here
+    }
+    c->deliveries.push_back({ h_dst, job, ev });
+    return 0;
+}
+
 int rr_copy_to_host_async(rr_ctx* c, const void* d_src, void* h_dst, size_t bytes, void* stream)
 {
     if (!c) return -1;
@@ -1486,18 +1537,9 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     const bool device_visible = host_visible(h_imgs_u8);
     // The default route: over the SDMA engines through ROCr, at once, behind this batch's assemble (ev_consumed) -- no shader
     // core stores a byte of it, so nothing has to be deferred or trickled, and it is the same engine under every HIP runtime
-    if (c->host_sdma && device_visible && !c->stats_mode) {
-        if (!c->sdma && !c->sdma_tried) {
-            c->sdma_tried = true;
-            std::string why;
-            c->sdma = sdma_create(c->device, L.d_img_u8.p, why);
-            if (!c->sdma && getenv("RR_HOST_SDMA_VERBOSE")) fprintf(stderr, "[rr] SDMA delivery not available: %s\n", why.c_str());
-        }
-        if (c->sdma && sdma_failed(c->sdma, nullptr)) {
-            if (getenv("RR_HOST_SDMA_VERBOSE")) { std::string why; (void)sdma_failed(c->sdma, &why); fprintf(stderr, "[rr] SDMA delivery switched off: %s\n", why.c_str()); }
-            c->host_sdma = 0;
-        } else if (c->sdma) {
-            L.sdma_job = sdma_submit(c->sdma, L.ev_consumed, L.d_img_u8.p, h_imgs_u8, bytes);
+    if (device_visible && !c->stats_mode) {
+        if (SdmaCopier* sd = sdma_of(c, L.d_img_u8.p)) {
+            L.sdma_job = sdma_submit(sd, L.ev_consumed, L.d_img_u8.p, h_imgs_u8, bytes);
             L.sdma_dst = h_imgs_u8;
             return 0;
         }
@@ -1526,6 +1568,14 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
     // oldest batch first (lanes are handed out round robin: the next one to be used holds the oldest batch): its images leave
     // while the younger batches still render, and only the youngest batch's copy is left when the kernels are done -- in lane
     // order the youngest batch may come first, and the copies of all the others then queue up behind the end of the run
+    for (size_t i = 0; i < c->deliveries.size();) {       // rr_deliver_to_host_async's copies
+        rr_ctx::Delivery& d = c->deliveries[i];
+        if (h_imgs_u8 != nullptr && d.dst != h_imgs_u8) { i++; continue; }
+        if (d.job && c->sdma) sdma_wait(c->sdma, d.job);
+        else RR_HIP(c, hipEventSynchronize(d.ev));
+        c->delivery_events.push_back(d.ev);
+        c->deliveries.erase(c->deliveries.begin() + (long)i);
+    }
     const size_t nl = c->lanes.size();
     for (size_t k = 0; k < nl; k++) {
         Lane& L = c->lanes[(c->next_lane + k) % nl];
@@ -1829,6 +1879,7 @@ int rr_synchronize(rr_ctx* c, void* stream)
     if (!c) return -1;
     RR_HIP(c, hipSetDevice(c->device));
     for (Lane& L : c->lanes) { int rc = flush_deferred(c, L); if (rc) return rc; }
+    if (!c->deliveries.empty()) { const int rc = rr_wait_host(c, nullptr); if (rc) return rc; }
     for (Lane& L : c->lanes) RR_HIP(c, hipStreamSynchronize(L.stream));
     RR_HIP(c, hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
     // batches may run on OTHER caller streams as well (the header recommends four): a frame there could set a

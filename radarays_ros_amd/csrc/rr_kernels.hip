@@ -1523,7 +1523,6 @@ __global__ __launch_bounds__(256) void k_score(const uint8_t* __restrict__ imgs,
 // with blockIdx % 8 == xcd work keeps the damage to one eighth of the chip.
 // grid `blocks` (8 x blocks when confined), block 64
 // ---------------------------------------------------------------------------
-template <int U>
 __global__ __launch_bounds__(1024) void k_copy_host(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int inflight, int xcd)
 {
     unsigned b = blockIdx.x, nb = gridDim.x;
@@ -1531,31 +1530,24 @@ __global__ __launch_bounds__(1024) void k_copy_host(const uint4* __restrict__ sr
         if ((int)(b & 7u) != xcd) return;
         b >>= 3; nb >>= 3;
     }
-    // U loads of 16 B per lane in flight, then their U stores: the loop is bound by the round trip of a load through a memory
-    // system the frame kernels keep busy (U = 1: 570-670 us per 11 MB beside them where the runtime's blit kernel takes 360)
+    // (more loads in flight per lane -- the loop unrolled 2 / 4 / 8 times -- were measured and change nothing: 24-25k images/s
+    // on config 2 in every shape; the runtime's own blit kernel is this very loop)
     const size_t nthreads = (size_t)nb * blockDim.x;
     int k = 0;
-    for (size_t i = (size_t)b * blockDim.x + threadIdx.x; i < n16; i += nthreads * U) {
-        uint4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) { const size_t e = i + (size_t)u * nthreads; if (e < n16) v[u] = src[e]; }
-#pragma unroll
-        for (int u = 0; u < U; u++) { const size_t e = i + (size_t)u * nthreads; if (e < n16) dst[e] = v[u]; }
-        if (inflight > 0 && (k += U) >= inflight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k = 0; }
+    for (size_t i = (size_t)b * blockDim.x + threadIdx.x; i < n16; i += nthreads) {
+        const uint4 v = src[i];
+        dst[i] = v;
+        if (inflight > 0 && ++k >= inflight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k = 0; }
     }
 }
-void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads, int unroll)
+void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads)
 {
     const size_t n16 = bytes / 16;
     if (n16 == 0) return;
     threads = std::max(64, std::min(1024, threads)) & ~63;
     unsigned g = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)blocks, (n16 + threads - 1) / threads));
     if (xcd >= 0) g *= 8u;
-    const uint4* a = reinterpret_cast<const uint4*>(src); uint4* d = reinterpret_cast<uint4*>(dst);
-    if (unroll >= 8) hipLaunchKernelGGL(k_copy_host<8>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
-    else if (unroll >= 4) hipLaunchKernelGGL(k_copy_host<4>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
-    else if (unroll >= 2) hipLaunchKernelGGL(k_copy_host<2>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
-    else hipLaunchKernelGGL(k_copy_host<1>, dim3(g), dim3(threads), 0, s, a, d, n16, inflight, xcd);
+    hipLaunchKernelGGL(k_copy_host, dim3(g), dim3(threads), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, inflight, xcd);
 }
 
 // what rr_simulate reports beside the image -- the frame's error bits / counters and its per-pass segment statistics -- into

@@ -456,8 +456,9 @@ int wait_slot(rr_multi* m, MultiSlot& S)
     if (!S.pending) return 0;
     const int n = (int)m->ctx.size();
     hipError_t e = hipSetDevice(m->devices[0]);
-    if (e == hipSuccess && n == 1 && !m->self_rccl) {
-        // the image may still sit on its frame lane (rr_simulate_batch_host_async defers the copy): deliver it
+    if (e == hipSuccess) {
+        // one device: the image may still sit on its frame lane or be on its way over SDMA (rr_simulate_batch_host_async);
+        // several: the root's copy is an rr_deliver_to_host_async job -- either way the context's fence completes it
         if (rr_wait_host(m->ctx[0], S.dst)) return fail_drained(m, -100, std::string("device ") + std::to_string(m->devices[0]) + ": " + rr_last_error(m->ctx[0]));
     }
     if (e == hipSuccess) e = hipEventSynchronize(S.ev_done);
@@ -612,8 +613,8 @@ int rr_multi_simulate_batch_async(rr_multi* m, const float* poses, int n_frames,
     RRM_TRY_HIP(S.d_imgs.ensure(bytes));
     { const int rc = rr_assemble_frames_device(m->ctx[0], d_cols, n_loc, block_stride, n_frames, frame_stride, S.d_imgs.p, S.streams[0]);
       if (rc) return fail_drained(m, rc, std::string("root: ") + rr_last_error(m->ctx[0])); }
-    // (the library's own copy kernel when the caller's buffer is page-locked, whichever HIP runtime serves the process)
-    { const int rc = rr_copy_to_host_async(m->ctx[0], S.d_imgs.p, out_imgs_u8, bytes, S.streams[0]);
+    // (over the SDMA engines, whichever HIP runtime serves the process: rr_deliver_to_host_async; fenced in wait_slot)
+    { const int rc = rr_deliver_to_host_async(m->ctx[0], S.d_imgs.p, out_imgs_u8, bytes, S.streams[0]);
       if (rc) return fail_drained(m, rc, std::string("root: ") + rr_last_error(m->ctx[0])); }
     RRM_TRY_HIP(hipEventRecord(S.ev_done, S.streams[0]));
 #undef RRM_TRY_HIP

@@ -163,11 +163,12 @@ class AzimuthShard:
         return s.images
 
     def _deliver(self, s):
-        """slot.images -> slot.host on the slot's stream: the library's own copy kernel (rr_copy_to_host_async: the delivered
-        rate then does not depend on which engine the process' HIP runtime would pick for a hipMemcpyAsync); a context
-        without it (the mock of the CPU tests) gets torch's copy"""
-        if s.stream is not None and hasattr(self.ctx, "copy_to_host_async"):
-            self.ctx.copy_to_host_async(s.images.data_ptr(), s.host.data_ptr(), s.images.numel(), s.stream.cuda_stream)
+        """slot.images -> slot.host behind the slot's stream, over the SDMA engines (rr_deliver_to_host_async: the delivered rate
+        then does not depend on which engine the process' HIP runtime would pick for a hipMemcpyAsync); a context without it
+        (the mock of the CPU tests) gets torch's copy"""
+        if s.stream is not None and hasattr(self.ctx, "deliver_to_host_async"):
+            self.ctx.deliver_to_host_async(s.images.data_ptr(), s.host.data_ptr(), s.images.numel(), s.stream.cuda_stream)
+            self._delivered = True          # fenced by ctx.wait_host, not by the stream (the copy runs on the SDMA engines)
         else:
             s.host.copy_(s.images, non_blocking=True)
 
@@ -185,6 +186,9 @@ class AzimuthShard:
         for s in self.slots:
             if s.stream is not None:
                 s.stream.synchronize()
+        if getattr(self, "_delivered", False):
+            self.ctx.wait_host(None)
+            self._delivered = False
 
     def host_images(self, step_no):
         """The host tensor [fpr][n_cells][n_angles] holding this rank's images of step `step_no`, or None when that step has

@@ -209,3 +209,32 @@ def test_gpu_fresnel_split_against_the_oracle_on_the_reference_derived_cases(nat
         assert np.allclose(re2[ok], 0.37 * re[ok], rtol=1e-14, atol=0) and np.array_equal(td2.view(np.uint32), td.view(np.uint32))
     print("fresnel GPU vs oracle (cases, flips, dir bit-equal, energy < 1e-12, NaN mismatches, max |dE|):", report)
     c.close()
+
+
+def test_stack_free_traversal_renders_the_same_bytes(native_lib, oracle, monkeypatch):
+    """RR_STACKLESS=1: k_trace walks the tree without a stack (traverse_stackless: parent links, children in key order, a node
+    re-fetched each time the walk returns to it; no LDS) -- the traversal north_star names, measured in round 6 at 1.7x the
+    launch time of the stack walk and therefore not the default.  The nearest hit is the minimum over (t, face id) whatever
+    the walk, so frames are byte-identical: a 3-pass frame of a scene with penetrable buildings, counts included, on both
+    builders' trees."""
+    s = scenes.heightfield_room(64, n_buildings=40, seed=3)
+    cfg = params.kaist_preset(n_reflections=3, n_samples=64, ambient_noise=2)
+    noise = (np.random.RandomState(2).uniform(0, 1, 400) * 1000.0).astype(np.float32)
+    pose = scenes.trajectory(5, s["name"])[2]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RR_STACKLESS", mode)
+        for builder in ("host", "gpu"):
+            c = native_lib.Context(0)
+            c.set_mesh(s["verts"], s["faces"], s["face_object_id"], builder=builder)
+            c.set_materials(materials_for(s), s["object_materials"], 0)
+            c.set_config(cfg)
+            c.set_beam_samples(golden_beams(64))
+            c.set_noise_offsets(noise)
+            out[(mode, builder)] = c.simulate(pose, want_f32=True)
+            c.close()
+    ref8, reff, refst = out[("0", "host")]
+    assert refst["hits"] > 10000 and refst["overflow"] == 0
+    for k, (g8, gf, st) in out.items():
+        assert np.array_equal(g8, ref8) and np.array_equal(gf.view(np.uint32), reff.view(np.uint32)), k
+        assert (st["wave_passes"], st["hits"], st["signals"]) == (refst["wave_passes"], refst["hits"], refst["signals"]), k

@@ -48,10 +48,13 @@ def test_traversal_and_shading_keep_eight_waves_per_simd(usage):
         stats = name.split("k_traceILb")[1][4] == "1"
         if not stats:
             assert u["vgpr"] <= 64 and u["occupancy"] == 8, (name, u)
-    later = [u for n, u in usage.items() if n.startswith("_ZN2rr7k_traceILb0ELb0ELb0ELb1EEEvNS_6ParamsEi")]
+    later = [u for n, u in usage.items() if n.startswith("_ZN2rr7k_traceILb0ELb0ELb0ELb1ELb0EEEvNS_6ParamsEi")]
     assert len(later) == 1, sorted(usage)
     later = later[0]
     assert later["vgpr"] <= 58 and later["sgpr"] <= 48, later                 # round 5: 57 / 42 (53 / 36 before the grazing guard)
+    # the stack-free walk (RR_STACKLESS=1, round 6): no LDS at all, still 8 waves per SIMD
+    sl = [u for n, u in usage.items() if n.startswith("_ZN2rr7k_traceILb0ELb0ELb0ELb0ELb1EEEvNS_6ParamsEi")]
+    assert len(sl) == 1 and sl[0]["lds"] == 0 and sl[0]["vgpr"] <= 60 and sl[0]["occupancy"] == 8 and sl[0]["scratch"] == 0, sl
     for name, u in find("k_shadeILb").items():
         assert u["vgpr"] <= 64 and u["occupancy"] == 8, (name, u)
     for name, u in find("k_columnILi").items():
