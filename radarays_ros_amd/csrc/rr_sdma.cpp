@@ -25,6 +25,7 @@
 #include <link.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -108,6 +109,11 @@ struct SdmaCopier {
                 cv_job.wait(lk, [&] { return quit || !q.empty(); });
                 if (q.empty()) return;                 // quit, nothing left
                 j = q.front();
+                if (quit) {                            // the context is being destroyed: images nobody waited for are dropped (their
+                    q.pop_front(); done_id = j.id;     // buffers may be gone already), the header's rule for rr_destroy
+                    cv_done.notify_all();
+                    continue;
+                }
             }
             // the kernels that produce the image first (the streams are non-blocking: nothing else orders a copy behind them)
             bool ok = true;
@@ -123,8 +129,15 @@ struct SdmaCopier {
                     const hsa_status_t st = api.async_copy(j.dst, pi.agentOwner, j.src, gpu, j.bytes, 0, nullptr, sig);
                     if (st != HSA_STATUS_SUCCESS) { ok = false; why = "hsa_amd_memory_async_copy: status " + std::to_string((int)st); }
                     else {
-                        const hsa_signal_value_t v = api.signal_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
-                        if (v < 0) { ok = false; why = "the SDMA copy reported an error through its completion signal"; }
+                        // (bounded waits: a copy that never completes must not hang the caller's rr_wait_host for ever)
+                        hsa_signal_value_t v = 1;
+                        const auto t0 = std::chrono::steady_clock::now();
+                        while (v >= 1) {
+                            v = api.signal_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, 50000000ull, HSA_WAIT_STATE_BLOCKED);
+                            if (v >= 1 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+                        }
+                        if (v >= 1) { ok = false; why = "the SDMA copy did not complete within 20 s"; }
+                        else if (v < 0) { ok = false; why = "the SDMA copy reported an error through its completion signal"; }
                     }
                 }
             }
@@ -157,7 +170,7 @@ void sdma_destroy(SdmaCopier* s)
     if (!s) return;
     { std::lock_guard<std::mutex> lk(s->mu); s->quit = true; }
     s->cv_job.notify_all();
-    if (s->th.joinable()) s->th.join();        // (drains the queue first: every job waits for its event, which the caller's rr_destroy has let complete)
+    if (s->th.joinable()) s->th.join();        // (a copy in flight completes; queued ones are dropped: rr_destroy drops images nobody waited for)
     (void)s->api.signal_destroy(s->sig);
     delete s;
 }

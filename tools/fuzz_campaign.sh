@@ -2,7 +2,7 @@
 # GPU box helper: the round's fuzz / soak campaign against the in-tree library; log -> gpurun_out/<tag>_fuzz.log
 # usage: tools/fuzz_campaign.sh <tag> [scale = 1]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; mkdir -p gpurun_out
-tag=${1:-r05}; k=${2:-1}; L=gpurun_out/${tag}_fuzz.log
+tag=${1:-r06}; k=${2:-1}; L=gpurun_out/${tag}_fuzz.log
 python - <<PY > $L
 import sys; sys.path.insert(0, "$R")
 import bench; print("kernel sources", bench.kernel_source_hash())
@@ -23,4 +23,11 @@ run python tools/soak_multi.py $((150 * k)) 3 3
 RR_MULTI_THREADS=0 run python tools/soak_multi.py $((200 * k)) 5 2
 RR_TIGHT_FORCE=2 run python tests/fuzz/fuzz_batch.py $((200 * k)) 91
 RR_GRAPHS=0 run python tests/fuzz/fuzz_state.py $((300 * k)) 91
+# round 6: the routes the host delivery can take, launch graphs replayed by ONE lane with changing poses, the stack-free traversal
+RR_HOST_SDMA=0 run python tools/soak_host.py $((300 * k)) 4
+RR_HOST_SDMA=0 RR_FLUSH_KERNEL=0 run python tools/soak_host.py $((200 * k)) 2
+run python tools/soak_host.py $((600 * k)) 2
+RR_LANES=1 run python tools/soak.py $((1500 * k)) 4
+RR_STACKLESS=1 run python tests/fuzz/fuzz_diff2.py $((600 * k)) 77
+RR_STACKLESS=1 run python tests/fuzz/fuzz_batch.py $((150 * k)) 77
 cat $L
