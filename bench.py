@@ -827,6 +827,7 @@ def main(argv=None):
                        "images": "delivered to page-locked host memory; timed through the last D2H copy (SURVEY §8d bracket = the reference's stopwatch, RadarCPU.cpp:147-550)",
                        "d2h_GBps": round(img_per_s * cfg.n_cells * params.N_ANGLES / 1e9, 3),
                        "hip_runtime": runtime,
+                       "host_delivery": (ctx.host_delivery_route() if hasattr(ctx, "host_delivery_route") else None),
                        "sharding": ("single GPU" if world == 1 else
                                     "azimuth columns x%d, 1 frame/batch + 1 all-gather" % world if args.strong else
                                     "azimuth columns x%d, %d frames/batch, 1 all_to_all/batch (frame f -> rank f)" % (world, fpb))},

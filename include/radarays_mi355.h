@@ -240,6 +240,10 @@ int rr_copy_to_host_async(rr_ctx* ctx, const void* d_src, void* h_dst, size_t by
  * (NULL: everything outstanding) or rr_synchronize().  Where the SDMA path is not available it is rr_copy_to_host_async plus
  * an event.  rr_multi's root and the sharded step loop's flush deliver this way. */
 int rr_deliver_to_host_async(rr_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
+/* Which route the host deliveries of this context take: 2 = SDMA through ROCr (csrc/rr_sdma.cpp) is in use; 1 = it will be
+ * tried by the first delivery; 0 = stream-ordered copies (RR_HOST_SDMA=0, or the path was not available / was switched off --
+ * RR_HOST_SDMA_VERBOSE=1 says why).  bench.py prints it on its line, the GPU tests assert it. */
+int rr_host_delivery_route(rr_ctx* ctx);
 
 /* Assemble the mono8 image from column-major columns, applying scroll_image
  * (RadarCPU.cpp:457): d_img[c][(scroll + a) % n_angles] = d_cols[a][c].

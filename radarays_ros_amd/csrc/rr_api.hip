@@ -1466,6 +1466,14 @@ int rr_deliver_to_host_async(rr_ctx* c, const void* d_src, void* h_dst, size_t b
     return 0;
 }
 
+int rr_host_delivery_route(rr_ctx* c)
+{
+    if (!c) return -1;
+    if (c->sdma && c->host_sdma && !sdma_failed(c->sdma, nullptr)) return 2;      // SDMA through ROCr: in use
+    if (c->host_sdma && !c->sdma_tried) return 1;                                  // ... will be tried by the first delivery
+    return 0;                                                                      // stream-ordered copies (deferred / trickled / copy kernel)
+}
+
 int rr_copy_to_host_async(rr_ctx* c, const void* d_src, void* h_dst, size_t bytes, void* stream)
 {
     if (!c) return -1;

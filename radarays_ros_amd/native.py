@@ -22,7 +22,7 @@ SYMBOLS = [
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
     "rr_set_stats_mode", "rr_debug_trace", "rr_debug_fresnel", "rr_get_bvh_info", "rr_get_trace_grid", "rr_get_graph_stats", "rr_set_timing_mode",
     "rr_get_kernel_time", "rr_get_kernel_samples", "rr_reserve_timing_events",
-    "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_copy_to_host_async", "rr_deliver_to_host_async", "rr_partition", "rr_multi_plan",
+    "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_copy_to_host_async", "rr_deliver_to_host_async", "rr_host_delivery_route", "rr_partition", "rr_multi_plan",
     "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_rccl_version", "rr_multi_ctx",
     "rr_multi_set_mesh", "rr_multi_set_mesh_gpu", "rr_multi_set_materials", "rr_multi_set_config", "rr_multi_set_beam_samples",
     "rr_multi_set_noise_offsets", "rr_multi_set_motion_poses", "rr_multi_simulate", "rr_multi_simulate_batch",
@@ -146,6 +146,7 @@ def lib():
     L.rr_wait_host.argtypes = [vp, vp]
     L.rr_copy_to_host_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.rr_deliver_to_host_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.rr_host_delivery_route.argtypes = [vp]
     L.rr_host_alloc.restype = vp
     L.rr_host_alloc.argtypes = [C.c_size_t]
     L.rr_host_free.argtypes = [vp]
@@ -343,6 +344,10 @@ class Context:
     def copy_to_host_async(self, d_src_ptr, h_dst_ptr, nbytes, stream=None):
         """device -> host on `stream` by the library's own copy kernel (page-locked destination) -- rr_copy_to_host_async"""
         self._ck(lib().rr_copy_to_host_async(self._h, C.c_void_p(d_src_ptr), C.c_void_p(h_dst_ptr), C.c_size_t(nbytes), C.c_void_p(stream)))
+
+    def host_delivery_route(self):
+        """rr_host_delivery_route: "sdma" (ROCr's SDMA path in use), "sdma (untried)" or "stream copies" (deferred / trickled / copy kernel)"""
+        return {2: "sdma", 1: "sdma (untried)", 0: "stream copies"}.get(int(lib().rr_host_delivery_route(self._h)), "?")
 
     def deliver_to_host_async(self, d_src_ptr, h_dst_ptr, nbytes, stream=None):
         """device -> page-locked host over SDMA once `stream` has got here; complete after wait_host(h_dst_ptr) -- rr_deliver_to_host_async"""

@@ -135,6 +135,7 @@ def test_host_delivery_routes(native_lib, monkeypatch, passes, flush):
     for k in range(NB):
         for j in range(4):
             assert np.array_equal(bufs[k].array[j], ref[(k + j) % 6]), (k, j)
+    assert c.host_delivery_route() == ("sdma" if flush[0] == "sdma" else "stream copies")     # no silent fallback
     c.synchronize()
     for b in bufs:
         b.close()

@@ -24,6 +24,7 @@ RR_MULTI_THREADS=0 run python tools/soak_multi.py $((200 * k)) 5 2
 RR_TIGHT_FORCE=2 run python tests/fuzz/fuzz_batch.py $((200 * k)) 91
 RR_GRAPHS=0 run python tests/fuzz/fuzz_state.py $((300 * k)) 91
 # round 6: the routes the host delivery can take, launch graphs replayed by ONE lane with changing poses, the stack-free traversal
+run python tests/fuzz/fuzz_trace.py $((300 * k)) 100000      # spatially split faces at grazing incidence
 RR_HOST_SDMA=0 run python tools/soak_host.py $((300 * k)) 4
 RR_HOST_SDMA=0 RR_FLUSH_KERNEL=0 run python tools/soak_host.py $((200 * k)) 2
 run python tools/soak_host.py $((600 * k)) 2
