@@ -509,6 +509,8 @@ void rr_free_mesh(rr_mesh* m);
  * RR_FLUSH_XCD (0)        ... the XCD all of them run on (PCIe-paced stores then fill the write queues of one XCD only); -1: all eight
  * RR_FOLD_MIN_BUSY (2)    other lanes that must be busy for a host copy to be folded into the next batch
  * RR_CULL_POP (1)         later passes drop stack entries at pop time by their distance bound; 0: off (same images)
+ * RR_GRAPH_GUARD (1)      launch graphs: two execs per shape used alternately, the host waits for an exec's previous launch before it re-sets
+ *                         its poses; 0 (probe): one exec, no wait -- relies on in-flight launches being unaffected by node updates
  * RR_GRAPHS (1)           launch chains of pose batches captured and replayed as hipGraphs (rr_get_graph_stats); 0: kernel by kernel
  * RR_TIGHT_GRID (1)       later-pass trace rows sized by the history of earlier batches (rr_get_trace_grid); 0: the doubling bound
  * RR_TRACE_CHUNK (16)     later-pass trace launches walk chunks of S neighbouring azimuths with the azimuth as the fast grid dimension;

@@ -38,7 +38,6 @@ void* trace0_kernel(bool spill, bool stackless);
 Params trace0_params(const Params& P);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
 void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads);
-void launch_frame_report(const Counters* cnt, const SegStats* ss, size_t n_ss, void* h_dst, hipStream_t s);
 void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s);
 void launch_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
                           float* out_rdir, double* out_re, float* out_tdir, double* out_te, hipStream_t s);
@@ -133,9 +132,14 @@ struct Lane {
     // a batch's images stay in d_img_u8 ("deferred") until the lane's NEXT host-delivery batch, whose later-pass trace
     // launches carry the copy (see Params::copy_src); rr_wait_host / rr_synchronize / any other use of the lane flush a
     // deferred copy with a plain hipMemcpyAsync
-    // ... or, the default: the batch's images leave at once over SDMA (rr_sdma.cpp), job `sdma_job` (0: none) into `sdma_dst`;
-    // the lane's next user waits for the job on the host before it lets anything overwrite d_img_u8
-    uint64_t sdma_job = 0; const void* sdma_dst = nullptr;
+    // ... or, the default: the batch's images leave at once over SDMA (rr_sdma.cpp).  TWO image buffers per lane, used alternately
+    // (d_img_u8 and d_img_u8_b), each with its event (behind the assemble that filled it) and the job that empties it: a buffer
+    // is written again two uses of the lane later (eight batches with four lanes), by which time its copy has long left -- the
+    // host checks the job before it reuses the buffer and practically never has to wait (with ONE buffer it waited for the lane's
+    // previous batch every time: the lane's stream ran dry while the host issued the next chain -- 35.9k instead of 39.4k images/s
+    // on config 2 from a C++ caller, 2.5k instead of 4.3k with one pose per batch on the target)
+    DevBuf<uint8_t> d_img_u8_b; hipEvent_t ev_img[2] = { nullptr, nullptr }; int img_flip = 0;
+    uint64_t sdma_job[2] = { 0, 0 }; const void* sdma_dst[2] = { nullptr, nullptr };
     bool deferred = false;
     uint8_t* def_dst = nullptr; size_t def_bytes = 0; hipStream_t def_stream = nullptr; bool def_foldable = false;
 };
@@ -236,6 +240,7 @@ struct rr_ctx {
     int tight_grid = 1;          // later-pass trace rows sized by what earlier batches needed (RR_TIGHT_GRID=0: the doubling bound)
     int tight_force = 0;         // RR_TIGHT_FORCE=n: rows of n workgroups whatever the history says (tests of the repair path)
     int hist_gen = 1;            // bumped whenever mesh / materials / beam / config change: the lanes' histories start over
+    int graph_guard = 1;         // RR_GRAPH_GUARD=0 (probe): replay ONE exec per shape without waiting for its previous launch, as round 5 did
     int use_graphs = 1;          // RR_GRAPHS=0: every launch chain is issued kernel by kernel
     int graph_gen = 1;           // bumped whenever anything a captured launch bakes in may have changed (tables, tree, lane buffers)
     uint64_t graph_clock = 0, graph_replays = 0, graph_captures = 0;
@@ -635,15 +640,19 @@ bool host_visible(const void* p)
 // the lane's deferred host copy, now, as a plain copy on the stream its batch ran on
 // the images the lane's last host-delivery batch handed to the SDMA worker have left d_img_u8 (host wait; over long before a
 // lane comes round again)
-void settle_sdma(rr_ctx* c, Lane& L)
+void settle_sdma(rr_ctx* c, Lane& L, int slot = -1, const void* only_dst = nullptr)
 {
-    if (L.sdma_job && c->sdma) sdma_wait(c->sdma, L.sdma_job);
-    L.sdma_job = 0; L.sdma_dst = nullptr;
+    for (int b = 0; b < 2; b++) {
+        if ((slot >= 0 && b != slot) || !L.sdma_job[b]) continue;
+        if (only_dst && L.sdma_dst[b] != only_dst) continue;
+        if (c->sdma) sdma_wait(c->sdma, L.sdma_job[b]);
+        L.sdma_job[b] = 0; L.sdma_dst[b] = nullptr;
+    }
 }
 
-int flush_deferred(rr_ctx* c, Lane& L)
+int flush_deferred(rr_ctx* c, Lane& L, bool settle = true)
 {
-    settle_sdma(c, L);
+    if (settle) settle_sdma(c, L);       // (every user of the lane but the SDMA route itself, which looks after its two buffers)
     if (!L.deferred) return 0;
     Lane::CopyRec* r = nullptr;
     int rc = take_rec(c, L, &r); if (rc) return rc;
@@ -878,12 +887,12 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
             hipKernelNodeParams kp = fg->pose_kp;
             kp.kernelParams = args; kp.extra = nullptr;
             hipError_t e = hipSuccess;
-            const int w = fg->flip; fg->flip ^= 1;
+            const int w = c->graph_guard ? fg->flip : 0; fg->flip ^= 1;
             hipGraphExec_t ex = w ? fg->ge2 : fg->ge;
-            if (fg->ev_pending[w]) { HostProfScope hp(6, "ctx:   graph: wait for the exec's previous launch"); e = hipEventSynchronize(fg->ev[w]); fg->ev_pending[w] = false; }
+            if (c->graph_guard && fg->ev_pending[w]) { HostProfScope hp(6, "ctx:   graph: wait for the exec's previous launch"); e = hipEventSynchronize(fg->ev[w]); fg->ev_pending[w] = false; }
             { HostProfScope hp(3, "ctx:   graph: set the poses"); if (e == hipSuccess) e = hipGraphExecKernelNodeSetParams(ex, fg->pose_node, &kp); }
             { HostProfScope hp(4, "ctx:   graph: launch"); if (e == hipSuccess) e = hipGraphLaunch(ex, s); }
-            if (e == hipSuccess) { e = hipEventRecord(fg->ev[w], s); fg->ev_pending[w] = e == hipSuccess; }
+            if (e == hipSuccess && c->graph_guard) { e = hipEventRecord(fg->ev[w], s); fg->ev_pending[w] = e == hipSuccess; }
             if (e != hipSuccess) return fail(c, -100, std::string("launch graph replay: ") + hipGetErrorString(e));
             c->graph_replays++;
             return 0;
@@ -966,6 +975,7 @@ rr_ctx* rr_create(int device)
     if (getenv("RR_TRACE_CHUNK")) c->seg_chunk = std::max(0, std::min(1024, atoi(getenv("RR_TRACE_CHUNK"))));
     if (getenv("RR_COPY_BLOCKS")) c->copy_blocks = std::max(0, std::min(26, atoi(getenv("RR_COPY_BLOCKS"))));
     if (getenv("RR_GRAPHS")) c->use_graphs = atoi(getenv("RR_GRAPHS")) != 0;
+    if (getenv("RR_GRAPH_GUARD")) c->graph_guard = atoi(getenv("RR_GRAPH_GUARD")) != 0;
     if (getenv("RR_FLUSH_KERNEL")) c->flush_kernel = atoi(getenv("RR_FLUSH_KERNEL")) != 0;
     if (getenv("RR_HOST_COPY_STREAM")) c->host_copy_stream = atoi(getenv("RR_HOST_COPY_STREAM"));
     if (getenv("RR_HOST_SDMA")) c->host_sdma = atoi(getenv("RR_HOST_SDMA")) != 0;
@@ -989,6 +999,8 @@ rr_ctx* rr_create(int device)
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&L.ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.ev_consumed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L.ev_img[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L.ev_img[1], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.rec[0].ev, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.rec[1].ev, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "rr_create: lane stream/event creation failed"; rr_destroy(c); return nullptr;
@@ -1019,6 +1031,8 @@ void rr_destroy(rr_ctx* c)
         drop_graphs(L); L.d_poses.release();
         if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
         if (L.ev_consumed) (void)hipEventDestroy(L.ev_consumed);
+        for (hipEvent_t e : L.ev_img) if (e) (void)hipEventDestroy(e);
+        L.d_img_u8_b.release();
         for (Lane::CopyRec& r : L.rec) if (r.ev) (void)hipEventDestroy(r.ev);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -1495,6 +1509,33 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     Lane& L = c->lanes[li];
     c->last_lane = li;
     const size_t bytes = (size_t)n_frames * g.n_cells * g.n_angles;
+    // The default route: over the SDMA engines through ROCr, at once, behind this batch's assemble -- no shader core stores a
+    // byte of it, so nothing has to be deferred or trickled, and it is the same engine under every HIP runtime
+    const bool device_visible = host_visible(h_imgs_u8);
+    if (SdmaCopier* sd = (device_visible && !c->stats_mode) ? sdma_of(c, c->d_bvh.p) : nullptr) {
+        rc = flush_deferred(c, L, false); if (rc) return rc;     // (images an earlier batch left on the lane by the other route)
+        const int b = L.img_flip;
+        settle_sdma(c, L, b);                                   // the job that empties THIS buffer: two uses of the lane ago
+        DevBuf<uint8_t>& img = b ? L.d_img_u8_b : L.d_img_u8;
+        if (img.n < bytes) {
+            settle_sdma(c, L);
+            RR_HIP(c, hipDeviceSynchronize());
+            RR_HIP(c, img.ensure(bytes));
+        }
+        if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));   // the lane's previous batch (its frame buffers)
+        rc = run_frame(c, L, poses, 0, g.n_angles, nullptr, nullptr, s, n_frames); if (rc) return rc;
+        { TimedScope t(c, s, "assemble");
+          launch_assemble_u8(L.d_cols_u8.p, img.p, g.n_angles, g.n_cells, g.scroll_image, s, g.n_angles,
+                             (size_t)g.n_angles * g.n_cells, n_frames, (size_t)g.n_angles * g.n_cells); }
+        RR_HIP(c, hipGetLastError());
+        RR_HIP(c, hipEventRecord(L.ev_consumed, s));
+        L.pending_consume = true;
+        RR_HIP(c, hipEventRecord(L.ev_img[b], s));
+        L.sdma_job[b] = sdma_submit(sd, L.ev_img[b], img.p, h_imgs_u8, bytes);
+        L.sdma_dst[b] = h_imgs_u8;
+        L.img_flip ^= 1;
+        return 0;
+    }
     settle_sdma(c, L);
     if (L.pending_consume) RR_HIP(c, hipStreamWaitEvent(s, L.ev_consumed, 0));   // the lane's previous batch, incl. its assemble
     // the images the lane's previous batch left behind ride on this batch's later-pass launches when possible
@@ -1542,16 +1583,6 @@ int rr_simulate_batch_host_async(rr_ctx* c, const float* poses, int n_frames, ui
     // they fill its write queues the stores of every other kernel wait behind them.  So the copy is DEFERRED to the lane's
     // next batch and trickled out by a few waves of its later-pass trace launches with ONE store per wave in flight
     // (k_trace, Params::copy_src): 3,980-4,025 images/s, within 1 % of the HBM-resident rate.
-    const bool device_visible = host_visible(h_imgs_u8);
-    // The default route: over the SDMA engines through ROCr, at once, behind this batch's assemble (ev_consumed) -- no shader
-    // core stores a byte of it, so nothing has to be deferred or trickled, and it is the same engine under every HIP runtime
-    if (device_visible && !c->stats_mode) {
-        if (SdmaCopier* sd = sdma_of(c, L.d_img_u8.p)) {
-            L.sdma_job = sdma_submit(sd, L.ev_consumed, L.d_img_u8.p, h_imgs_u8, bytes);
-            L.sdma_dst = h_imgs_u8;
-            return 0;
-        }
-    }
     if (c->host_copy_stream && g.n_reflections < 2) {
         // nothing later could carry these images: out they go now, on the copy stream, behind this batch's assemble; the lane's
         // next batch waits for the copy (device side) before it touches the lane
@@ -1587,7 +1618,7 @@ int rr_wait_host(rr_ctx* c, const void* h_imgs_u8)
     const size_t nl = c->lanes.size();
     for (size_t k = 0; k < nl; k++) {
         Lane& L = c->lanes[(c->next_lane + k) % nl];
-        if (L.sdma_job && (h_imgs_u8 == nullptr || L.sdma_dst == h_imgs_u8)) settle_sdma(c, L);
+        settle_sdma(c, L, -1, h_imgs_u8);
         if (L.deferred && (h_imgs_u8 == nullptr || L.def_dst == h_imgs_u8)) { int rc = flush_deferred(c, L); if (rc) return rc; }
         for (Lane::CopyRec& r : L.rec)
             if (r.pending && (h_imgs_u8 == nullptr || r.dst == h_imgs_u8)) {
@@ -1998,9 +2029,12 @@ int rr_simulate(rr_ctx* c, const float pose[7], int az_begin, int az_end,
         RR_HIP(c, hipMemcpyAsync(h8.data(), L.d_cols_u8.p, h8.size(), hipMemcpyDeviceToHost, c->stream));
         if (out_f32) RR_HIP(c, hipMemcpyAsync(hf.data(), L.d_cols_f32.p, hf.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
-    // error bits / counters and the per-pass statistics: one kernel's stores into the page-locked block
-    launch_frame_report(L.d_counters.p, L.d_seg_stats.p, (stats && L.d_seg_stats.p && g.n_reflections > 0) ? n_st : 0, c->h_frame, c->stream);
-    RR_HIP(c, hipGetLastError());
+    // error bits / counters and the per-pass statistics ride home behind the image.  (Round 6 tried ONE kernel storing both into
+    // the page-locked block instead -- k_frame_report, no copy engine involved: 0.151 instead of 0.139-0.141 ms per call on
+    // config 2.  This is the latency path; the small copies stay.)
+    RR_HIP(c, hipMemcpyAsync(h_cnt, L.d_counters.p, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    if (stats && L.d_seg_stats.p && g.n_reflections > 0)
+        RR_HIP(c, hipMemcpyAsync(h_ss, L.d_seg_stats.p, n_st * sizeof(SegStats), hipMemcpyDeviceToHost, c->stream));
     RR_HIP(c, hipEventRecord(L.ev_consumed, c->stream));
     L.pending_consume = true;
     RR_HIP(c, hipStreamSynchronize(c->stream));

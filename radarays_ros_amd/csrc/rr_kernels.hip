@@ -1550,26 +1550,9 @@ void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int 
     hipLaunchKernelGGL(k_copy_host, dim3(g), dim3(threads), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, inflight, xcd);
 }
 
-// what rr_simulate reports beside the image -- the frame's error bits / counters and its per-pass segment statistics -- into
-// ONE page-locked block (Counters, then n_ss SegStats): a kernel's stores instead of two small hipMemcpyAsync
-__global__ __launch_bounds__(256) void k_frame_report(const Counters* __restrict__ cnt, const SegStats* __restrict__ ss, size_t n_ss, void* h_dst)
-{
-    static_assert(sizeof(Counters) % 16 == 0 && sizeof(SegStats) == 16, "report layout");
-    const uint4* a = reinterpret_cast<const uint4*>(cnt);
-    uint4* d = reinterpret_cast<uint4*>(h_dst);
-    constexpr size_t nc = sizeof(Counters) / 16;
-    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
-    for (size_t i = i0; i < nc; i += stride) d[i] = a[i];
-    const uint4* b = reinterpret_cast<const uint4*>(ss);
-    for (size_t i = i0; i < n_ss; i += stride) d[nc + i] = b[i];
-}
+// rr_peek_error_bits_async: one word into a page-locked host word, by a kernel's store (no copy engine involved)
 __global__ void k_store_u32(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) { *dst = *src; }
 void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, src, h_dst); }
-void launch_frame_report(const Counters* cnt, const SegStats* ss, size_t n_ss, void* h_dst, hipStream_t s)
-{
-    const unsigned g = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (n_ss + 255) / 256));
-    hipLaunchKernelGGL(k_frame_report, dim3(g), dim3(256), 0, s, cnt, ss, n_ss, h_dst);
-}
 
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s)
 {
