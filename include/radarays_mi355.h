@@ -206,11 +206,12 @@ int rr_simulate_batch_device(rr_ctx* ctx, const float* poses, int n_frames, uint
  * h_imgs_u8 = [n_frames][n_cells][n_angles].  Returns at once; the images are COMPLETE ONLY after rr_wait_host(ctx,
  * h_imgs_u8) (NULL: every outstanding buffer) or rr_synchronize() -- until then the buffer must stay valid and must not be
  * read.  How the bytes travel is the library's business.  By default they leave at once over the SDMA engines, submitted
- * through ROCr by a worker thread of the context behind the batch's last kernel (csrc/rr_sdma.cpp): no shader core stores a byte
- * of them, and it is the same engine whichever HIP runtime serves the process (a ROCm 7.0.2 runtime, e.g. the one a Python ML wheel bundles, would
- * carry a hipMemcpyAsync as a blit kernel: 27-35k images/s on config 2 where SDMA delivers the link's 39k).  Where that path
- * is not available (RR_HOST_SDMA=0, a pageable buffer, no reachable ROCr) a batch's images wait in device memory and ride out on the
- * trace launches of the next batch that uses the same frame lane (a few waves trickle them over PCIe with one store in
+ * through ROCr by worker threads of the context behind the batch's last kernel (csrc/rr_sdma.cpp; two image buffers per
+ * frame lane, so the host does not wait for a copy before it issues the lane's next batch): no shader core stores a byte of
+ * them, and it is the same engine whichever HIP runtime serves the process (a ROCm 7.0.2 runtime, e.g. the one a Python ML
+ * wheel bundles, would carry a hipMemcpyAsync as a blit kernel: 27-35k images/s on config 2 where SDMA delivers the link's
+ * 39k).  Where that path is not available (RR_HOST_SDMA=0, a pageable buffer, no reachable ROCr) a batch's images wait in
+ * device memory and ride out on the trace launches of the next batch that uses the same frame lane (a few waves trickle them over PCIe with one store in
  * flight each, which keeps the stores of the running kernels from queueing behind them: within 1 % of the rate with the
  * images left in HBM, where a plain copy behind each batch costs 7 %); rr_wait_host / rr_synchronize / any other use of
  * the lane send what is still waiting with a plain copy.  Issue batches on up to four streams (HIP maps streams onto
@@ -230,8 +231,9 @@ void  rr_host_free(void* p);
  * and the size are multiples of 16 -- else a plain hipMemcpyAsync.  Why an entry point: which engine carries a
  * hipMemcpyAsync to page-locked memory is the choice of the HIP runtime in the caller's process (a ROCm 7.0.2 runtime
  * launches a blit kernel per copy and reads 27-36k images/s on config 2, the image's own ROCm 7.2 uses SDMA: 39.4k);
- * every delivery of this library (rr_simulate_batch_host_async's deferred copies, rr_wait_host's flush, the sharded step
- * loop's flush_host) takes this route, so the delivered rate does not depend on it.  Replaces nothing in the reference
+ * the library's deliveries that must be STREAM-ordered take this route (the fallback copies of rr_simulate_batch_host_async
+ * where SDMA is not available); measured, a shader-core copy is no faster than the runtime's blit kernel (24-31k on config 2)
+ * -- callers that can fence with rr_wait_host use rr_deliver_to_host_async below.  Replaces nothing in the reference
  * (cv_bridge deep-copies m_polar_image on the host, RadarCPU.cpp:555-558). */
 int rr_copy_to_host_async(rr_ctx* ctx, const void* d_src, void* h_dst, size_t bytes, void* stream);
 /* The same for a caller that can fence with rr_wait_host instead of the stream: bytes of a caller-owned device buffer leave
@@ -500,6 +502,8 @@ void rr_free_mesh(rr_mesh* m);
  *                         a worker thread per context; page-locked destinations) -- the same engine under every HIP runtime; 0: the
  *                         deferred copies below (trickled out by the next batch's trace launches / the copy kernel).  RR_HOST_SDMA_VERBOSE=1
  *                         says on stderr why the path was not available or was switched off
+ * RR_SDMA_ACTIVE_US (600)  ... a worker waits this long actively for a copy's completion signal before it sleeps on it (0: sleeps at once;
+ *                         a blocked wait wakes tens of microseconds late on a busy host and the engine idles meanwhile)
  * RR_HOST_COPY_STREAM (0) 1: one-pass frames (nothing later could carry their images) are copied out at once on one dedicated stream
  * RR_FLUSH_KERNEL (1)     a host copy that does not ride on a trace launch (one-pass frames, the end of a run, rr_copy_to_host_async)
  *                         is stored by the library's own kernel when the destination is page-locked; 0: hipMemcpyAsync

@@ -853,6 +853,10 @@ int run_frame(rr_ctx* c, Lane& L, const float* pose, int az_begin, int az_end,
         }
         fg->last_use = ++c->graph_clock;
         if (!fg->ge && fg->hits >= 1) {            // the second call with this shape: worth a capture
+            // (No SDMA worker may be waiting on an event of this stream while it captures: the runtime treats a
+            // hipEventSynchronize on an event whose stream is capturing as an error and invalidates the capture -- found by
+            // fuzz_batch in round 6.  Captures are rare, once per shape: let the deliveries in flight finish first.)
+            if (c->sdma) sdma_wait_all(c->sdma);
             Params Q = P;
             hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {

@@ -27,6 +27,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -46,6 +47,7 @@ struct HsaApi {
     decltype(&hsa_signal_destroy) signal_destroy = nullptr;
     decltype(&hsa_signal_store_relaxed) signal_store = nullptr;
     decltype(&hsa_signal_wait_scacquire) signal_wait = nullptr;
+    decltype(&hsa_system_get_info) system_info = nullptr;       // (optional: the timestamp frequency, for the length of the active wait)
     bool ok() const { return pointer_info && async_copy && signal_create && signal_destroy && signal_store && signal_wait; }
 };
 
@@ -71,6 +73,7 @@ bool find_live_hsa(const void* device_ptr, HsaApi& api, hsa_agent_t& gpu, std::s
         a.signal_destroy = (decltype(a.signal_destroy))dlsym(h, "hsa_signal_destroy");
         a.signal_store = (decltype(a.signal_store))dlsym(h, "hsa_signal_store_relaxed");
         a.signal_wait = (decltype(a.signal_wait))dlsym(h, "hsa_signal_wait_scacquire");
+        a.system_info = (decltype(a.system_info))dlsym(h, "hsa_system_get_info");
         if (!a.ok()) continue;
         hsa_amd_pointer_info_t pi; std::memset(&pi, 0, sizeof(pi)); pi.size = sizeof(pi);
         if (a.pointer_info(const_cast<void*>(device_ptr), &pi, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS &&
@@ -103,6 +106,10 @@ struct SdmaCopier {
     uint64_t next_id = 1, done_upto = 0;      // every job <= done_upto is complete ...
     std::set<uint64_t> done_ahead;            // ... and these beyond it (two copies may finish out of order)
     bool quit = false;
+    // a copy of a batch's images takes ~200 us: the worker first waits for its completion signal ACTIVELY for `active_ticks` of the
+    // HSA timestamp clock (RR_SDMA_ACTIVE_US, default 600 us) -- a blocked wait is woken by an interrupt, tens of microseconds
+    // late on a busy host, and the engine idles until the next copy is submitted -- and only then goes to sleep
+    uint64_t active_ticks = 0;
     std::atomic<int> failed{0};
     std::string err;
 
@@ -132,7 +139,13 @@ struct SdmaCopier {
             // the kernels that produce the image first (the streams are non-blocking: nothing else orders a copy behind them)
             bool ok = true;
             std::string why;
-            if (hipEventSynchronize(j.after) != hipSuccess) { ok = false; why = "hipEventSynchronize failed"; (void)hipGetLastError(); }
+            if (hipEventSynchronize(j.after) != hipSuccess) {
+                // (e.g. the event's stream is being captured by the caller just now: the runtime refuses to wait on it.)  The image
+                // must not be copied before the kernels that write it are done: wait for the whole device instead, then deliver
+                // by a blocking copy below; the route is switched off, the caller's next deliveries take the stream-ordered one
+                ok = false; why = "hipEventSynchronize failed (is the stream being captured?)"; (void)hipGetLastError();
+                for (int tries = 0; tries < 2000 && hipDeviceSynchronize() != hipSuccess; tries++) { (void)hipGetLastError(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+            }
             if (ok && failed.load()) { ok = false; why = "an earlier job failed"; }
             if (ok) {
                 hsa_amd_pointer_info_t pi; std::memset(&pi, 0, sizeof(pi)); pi.size = sizeof(pi);
@@ -146,6 +159,7 @@ struct SdmaCopier {
                         // (bounded waits: a copy that never completes must not hang the caller's rr_wait_host for ever)
                         hsa_signal_value_t v = 1;
                         const auto t0 = std::chrono::steady_clock::now();
+                        if (active_ticks) v = api.signal_wait(sig[w], HSA_SIGNAL_CONDITION_LT, 1, active_ticks, HSA_WAIT_STATE_ACTIVE);
                         while (v >= 1) {
                             v = api.signal_wait(sig[w], HSA_SIGNAL_CONDITION_LT, 1, 50000000ull, HSA_WAIT_STATE_BLOCKED);
                             if (v >= 1 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
@@ -172,6 +186,12 @@ SdmaCopier* sdma_create(int hip_device, const void* any_device_ptr, std::string&
     SdmaCopier* s = new SdmaCopier();
     s->device = hip_device;
     if (!find_live_hsa(any_device_ptr, s->api, s->gpu, why)) { delete s; return nullptr; }
+    {
+        uint64_t freq = 100000000ull;          // 100 MHz unless the runtime says otherwise
+        if (s->api.system_info) { uint64_t f = 0; if (s->api.system_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &f) == HSA_STATUS_SUCCESS && f) freq = f; }
+        const long us = getenv("RR_SDMA_ACTIVE_US") ? atol(getenv("RR_SDMA_ACTIVE_US")) : 600;
+        s->active_ticks = us > 0 ? (uint64_t)((double)freq * 1e-6 * (double)us) : 0;
+    }
     int made = 0;
     for (; made < SdmaCopier::kWorkers; made++) if (s->api.signal_create(1, 0, nullptr, &s->sig[made]) != HSA_STATUS_SUCCESS) break;
     int started = 0;

@@ -239,3 +239,40 @@ def test_stack_free_traversal_renders_the_same_bytes(native_lib, oracle, monkeyp
     for k, (g8, gf, st) in out.items():
         assert np.array_equal(g8, ref8) and np.array_equal(gf.view(np.uint32), reff.view(np.uint32)), k
         assert (st["wave_passes"], st["hits"], st["signals"]) == (refst["wave_passes"], refst["hits"], refst["signals"]), k
+
+
+def test_launch_graph_capture_while_deliveries_are_in_flight(native_lib, monkeypatch):
+    """Found by fuzz_batch in round 6: a launch chain is CAPTURED (second use of a shape on a lane) on a stream whose earlier
+    batch still has an SDMA delivery pending -- the worker thread sits in hipEventSynchronize on an event of that very stream,
+    which the runtime refuses while the stream captures (the capture was invalidated and the entry point failed).  run_frame
+    now lets the deliveries in flight finish before it captures.  Host deliveries and device-path batches interleaved on two
+    streams over four lanes, shapes met for the first and second time all along: every image right, no error, and the SDMA
+    route still in use at the end (a refused wait would have switched it off)."""
+    import torch
+    monkeypatch.setenv("RR_HOST_SDMA_VERBOSE", "1")
+    s = scenes.heightfield_room(64, n_buildings=40, seed=3)
+    cfg = params.kaist_preset(n_reflections=3, n_samples=96, ambient_noise=2)
+    noise = (np.random.RandomState(5).uniform(0, 1, 400) * 1000.0).astype(np.float32)
+    c = _ctx(native_lib, s, cfg, materials_for(s), golden_beams(96), noise)
+    P = scenes.trajectory(7, s["name"])
+    ref = np.stack([c.simulate(p)[0] for p in P])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    rs = np.random.RandomState(1)
+    for K in (3, 5, 2):                                   # three batch sizes = three families of shapes to capture
+        poses = P[:K]
+        hosts = [native_lib.HostImages((K, cfg.n_cells, 400)) for _ in range(9)]
+        imgs = torch.zeros((K, cfg.n_cells, 400), dtype=torch.uint8, device="cuda:0")
+        for b in range(9):
+            ps = np.roll(np.asarray(poses), -b, axis=0)
+            c.simulate_batch_host_async(ps, hosts[b].ptr, streams[b % 2].cuda_stream)
+            if rs.randint(0, 2) == 0:
+                c.simulate_batch_device(poses, imgs.data_ptr(), streams[b % 2].cuda_stream)
+        for b in rs.permutation(9):
+            c.wait_host(hosts[int(b)].ptr)
+            assert np.array_equal(hosts[int(b)].array, np.roll(ref[:K], -int(b), axis=0)), (K, int(b))
+        c.synchronize(streams[0].cuda_stream); c.synchronize(streams[1].cuda_stream)
+        assert np.array_equal(imgs.cpu().numpy(), ref[:K])
+        for h in hosts:
+            h.close()
+    assert c.host_delivery_route() == "sdma" and c.graph_stats()[0] >= 3
+    c.close()
