@@ -502,8 +502,8 @@ void rr_free_mesh(rr_mesh* m);
  *                         a worker thread per context; page-locked destinations) -- the same engine under every HIP runtime; 0: the
  *                         deferred copies below (trickled out by the next batch's trace launches / the copy kernel).  RR_HOST_SDMA_VERBOSE=1
  *                         says on stderr why the path was not available or was switched off
- * RR_SDMA_ACTIVE_US (600)  ... a worker waits this long actively for a copy's completion signal before it sleeps on it (0: sleeps at once;
- *                         a blocked wait wakes tens of microseconds late on a busy host and the engine idles meanwhile)
+ * RR_SDMA_ACTIVE_US (0)    ... a worker waits this long actively for a copy's completion signal before it sleeps on it (measured: no
+ *                         gain with two workers, the other one has the next copy queued already)
  * RR_HOST_COPY_STREAM (0) 1: one-pass frames (nothing later could carry their images) are copied out at once on one dedicated stream
  * RR_FLUSH_KERNEL (1)     a host copy that does not ride on a trace launch (one-pass frames, the end of a run, rr_copy_to_host_async)
  *                         is stored by the library's own kernel when the destination is page-locked; 0: hipMemcpyAsync

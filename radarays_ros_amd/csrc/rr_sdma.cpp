@@ -106,9 +106,10 @@ struct SdmaCopier {
     uint64_t next_id = 1, done_upto = 0;      // every job <= done_upto is complete ...
     std::set<uint64_t> done_ahead;            // ... and these beyond it (two copies may finish out of order)
     bool quit = false;
-    // a copy of a batch's images takes ~200 us: the worker first waits for its completion signal ACTIVELY for `active_ticks` of the
-    // HSA timestamp clock (RR_SDMA_ACTIVE_US, default 600 us) -- a blocked wait is woken by an interrupt, tens of microseconds
-    // late on a busy host, and the engine idles until the next copy is submitted -- and only then goes to sleep
+    // RR_SDMA_ACTIVE_US > 0: the worker first waits for a copy's completion signal ACTIVELY for that long (in ticks of the HSA
+    // timestamp clock) before it sleeps on it -- a blocked wait is woken by an interrupt, possibly tens of microseconds late on a
+    // busy host.  Measured on the pool (config 2, 12 runs): 39.0-39.1k images/s with 600 or 2000 us, 39.0-39.25k with 0 -- with two
+    // workers the other one has the next copy queued already, so the default is 0: no core is burnt
     uint64_t active_ticks = 0;
     std::atomic<int> failed{0};
     std::string err;
@@ -189,7 +190,7 @@ SdmaCopier* sdma_create(int hip_device, const void* any_device_ptr, std::string&
     {
         uint64_t freq = 100000000ull;          // 100 MHz unless the runtime says otherwise
         if (s->api.system_info) { uint64_t f = 0; if (s->api.system_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &f) == HSA_STATUS_SUCCESS && f) freq = f; }
-        const long us = getenv("RR_SDMA_ACTIVE_US") ? atol(getenv("RR_SDMA_ACTIVE_US")) : 600;
+        const long us = getenv("RR_SDMA_ACTIVE_US") ? atol(getenv("RR_SDMA_ACTIVE_US")) : 0;
         s->active_ticks = us > 0 ? (uint64_t)((double)freq * 1e-6 * (double)us) : 0;
     }
     int made = 0;
