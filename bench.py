@@ -850,10 +850,11 @@ def main(argv=None):
             "launch_graphs": {"replays_in_timed_region": int(graphs_after[1] - graphs_before[1]),
                               "captures_in_timed_region": int(graphs_after[0] - graphs_before[0]),
                               "live_timing_events": bool(live_timing),
-                              "what": "chains replayed from hipGraphs inside the timed region.  0 on the multi-pass workloads by construction: "
-                                      "their chains carry the previous batch's host copy on their trace launches (pointers that move from "
-                                      "call to call) and, when the dominant kernel is a k_trace launch, begin / end events -- both are "
-                                      "issued kernel by kernel; `hbm_resident` and `single_pose` replay graphs"},
+                              "what": "chains replayed from hipGraphs inside the timed region.  0 where the dominant kernel is a k_trace "
+                                      "launch: its begin / end events (roofline.avg_launch_us is measured live) keep the chains kernel by "
+                                      "kernel -- GPU time is the same either way, a replay saves host time; `hbm_resident` and "
+                                      "`single_pose` replay graphs.  (In the fallback delivery route, RR_HOST_SDMA=0, the multi-pass chains "
+                                      "also carry the previous batch's host copy and are never replayed.)"},
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
