@@ -209,6 +209,7 @@ struct rr_ctx {
 
     int passes_override = -1;    // a parameter batch in the making: the largest n_reflections of its sets sizes queues and launch loops
     DevBuf<unsigned long long> d_sse; DevBuf<uint8_t> d_ref_img;     // rr_score_images / rr_simulate_param_sets
+    void* h_rb = nullptr; size_t h_rb_bytes = 0;         // page-locked: read_back()
     void* h_frame = nullptr; size_t h_frame_bytes = 0;   // page-locked: error bits + per-pass counters of rr_simulate's frame
 
     bool roctx = false;
@@ -637,6 +638,26 @@ bool host_visible(const void* p)
     return v;
 }
 
+// a small synchronous read-back of device words (counters, per-pass statistics) without asking the runtime for a copy: a kernel
+// stores them into a page-locked block of the context, the host copies from there.  The device must be idle on these words
+// (the callers have synchronised).  Sizes that are not multiples of 16 take hipMemcpy
+int read_back(rr_ctx* c, void* dst, const void* d_src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (!c->flush_kernel || bytes % 16 != 0 || (uintptr_t)d_src % 16 != 0) { RR_HIP(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return 0; }
+    if (c->h_rb_bytes < bytes) {
+        if (c->h_rb) (void)hipHostFree(c->h_rb);
+        c->h_rb = nullptr; c->h_rb_bytes = 0;
+        RR_HIP(c, hipHostMalloc(&c->h_rb, bytes + 4096, hipHostMallocDefault));
+        c->h_rb_bytes = bytes + 4096;
+    }
+    launch_copy_host(d_src, c->h_rb, bytes, 4, 0, -1, c->stream, 256);
+    RR_HIP(c, hipGetLastError());
+    RR_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(dst, c->h_rb, bytes);
+    return 0;
+}
+
 // the lane's deferred host copy, now, as a plain copy on the stream its batch ran on
 // the images the lane's last host-delivery batch handed to the SDMA worker have left d_img_u8 (host wait; over long before a
 // lane comes round again)
@@ -1043,6 +1064,7 @@ void rr_destroy(rr_ctx* c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_frame) (void)hipHostFree(c->h_frame);
+    if (c->h_rb) (void)hipHostFree(c->h_rb);
     delete c;
 }
 
@@ -1767,7 +1789,7 @@ int finish_param_batch(rr_ctx* c, int n_sets, uint8_t* out_imgs_u8, const uint8_
     }
     RR_HIP(c, hipStreamSynchronize(c->stream));
     Counters h;
-    RR_HIP(c, hipMemcpy(&h, c->lanes[c->last_lane].d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    { const int rcb = read_back(c, &h, c->lanes[c->last_lane].d_counters.p, sizeof(h)); if (rcb) return rcb; }
     if (h.overflow) RR_HIP(c, hipMemset(c->lanes[c->last_lane].d_sticky.p, 0, sizeof(uint32_t)));
     if (h.overflow & 1u) return fail(c, -7, "wave/signal queue capacity exceeded; raise rr_config.max_waves_per_azimuth");
     if (h.overflow & 2u) return fail(c, -8, "object id or material id out of range of the tables given to rr_set_materials");
@@ -1966,7 +1988,7 @@ int rr_get_stats(rr_ctx* c, rr_stats* st)
     Lane& L = c->lanes[c->last_lane];
     if (!L.d_counters.p) return 0;
     Counters h;
-    RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    { const int rcb = read_back(c, &h, L.d_counters.p, sizeof(h)); if (rcb) return rcb; }
     st->nodes_visited = h.nodes; st->tris_tested = h.tris; st->overflow = h.overflow;
     if (getenv("RR_TRACE_STATS")) fprintf(stderr, "[rr stats] waves %u wave_iters %llu (avg %.1f) max_iters %u\n", h.n_waves, h.wave_iters, h.n_waves ? (double)h.wave_iters / h.n_waves : 0.0, h.max_iters);
     if (getenv("RR_TRACE_STATS") && h.n_waves)
@@ -1976,7 +1998,7 @@ int rr_get_stats(rr_ctx* c, rr_stats* st)
     const size_t n = (size_t)L.last_n_seg * (size_t)L.last_n_passes;
     if (n && L.d_seg_stats.p) {
         std::vector<SegStats> ss(n);
-        RR_HIP(c, hipMemcpy(ss.data(), L.d_seg_stats.p, n * sizeof(SegStats), hipMemcpyDeviceToHost));
+        { const int rcb = read_back(c, ss.data(), L.d_seg_stats.p, n * sizeof(SegStats)); if (rcb) return rcb; }
         for (const SegStats& x : ss) { st->wave_passes += x.wave_passes; st->hits += x.hits; st->signals += x.signals; }
     }
     return 0;
@@ -2076,7 +2098,7 @@ int rr_get_traversal_shape(rr_ctx* c, uint64_t out[8])
     Lane& L = c->lanes[c->last_lane];
     if (!L.d_counters.p) return 0;
     Counters h;
-    RR_HIP(c, hipMemcpy(&h, L.d_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    { const int rcb = read_back(c, &h, L.d_counters.p, sizeof(h)); if (rcb) return rcb; }
     out[0] = h.n_waves; out[1] = h.it_all; out[2] = h.it_node; out[3] = h.it_leaf; out[4] = h.quad_steps; out[5] = h.max_iters;
     out[6] = h.nodes; out[7] = h.quad_steps > h.nodes ? h.quad_steps - h.nodes : 0;
     return 0;
