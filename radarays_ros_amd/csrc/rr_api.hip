@@ -38,6 +38,7 @@ void* trace0_kernel(bool spill, bool stackless);
 Params trace0_params(const Params& P);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
 void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads);
+void launch_copy_words(const void* src, void* dst, size_t bytes, hipStream_t s);
 void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s);
 void launch_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
                           float* out_rdir, double* out_re, float* out_tdir, double* out_te, hipStream_t s);
@@ -366,6 +367,27 @@ void beam_trace_orders(const float* beams, size_t nb, std::vector<uint32_t>& ord
     make_order(1, order2);
 }
 
+// a set-up table goes up through a page-locked staging block and a word-copy kernel on the NULL stream (ordered exactly like the
+// hipMemcpy it replaces, and complete on return): no dispatch of the runtime's own copy kernel is left in a run's kernel trace.
+// Larger than 4 MB, or not whole words: hipMemcpy
+hipError_t upload_table(rr_ctx* c, void* d_dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    if (!c->flush_kernel || bytes % 4 != 0 || bytes > ((size_t)4 << 20)) return hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice);
+    if (c->h_rb_bytes < bytes) {
+        if (c->h_rb) (void)hipHostFree(c->h_rb);
+        c->h_rb = nullptr; c->h_rb_bytes = 0;
+        hipError_t e = hipHostMalloc(&c->h_rb, bytes + 4096, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        c->h_rb_bytes = bytes + 4096;
+    }
+    std::memcpy(c->h_rb, src, bytes);
+    launch_copy_words(c->h_rb, d_dst, bytes, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+
 int upload_tables(rr_ctx* c)
 {
     if (!c->tables_dirty) return 0;
@@ -396,7 +418,7 @@ int upload_tables(rr_ctx* c)
         qas[k] = q;
     }
     RR_HIP(c, c->d_qas.ensure(qas.size()));
-    RR_HIP(c, hipMemcpy(c->d_qas.p, qas.data(), qas.size() * sizeof(float4), hipMemcpyHostToDevice));
+    RR_HIP(c, upload_table(c, c->d_qas.p, qas.data(), qas.size() * sizeof(float4)));
     }
 
     if (dirty & rr_ctx::D_BEAMS) {
@@ -404,14 +426,14 @@ int upload_tables(rr_ctx* c)
     std::vector<float4> b4(nb);
     for (size_t i = 0; i < nb; i++) b4[i] = make_float4(c->beams[3 * i], c->beams[3 * i + 1], c->beams[3 * i + 2], 0.0f);
     RR_HIP(c, c->d_beams.ensure(nb));
-    if (nb) RR_HIP(c, hipMemcpy(c->d_beams.p, b4.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
+    if (nb) RR_HIP(c, upload_table(c, c->d_beams.p, b4.data(), nb * sizeof(float4)));
     {
         std::vector<uint32_t> order, order2;
         beam_trace_orders(c->beams.data(), nb, order, order2);
         RR_HIP(c, c->d_beam_order2.ensure(nb));
-        if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order2.p, order2.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (nb) RR_HIP(c, upload_table(c, c->d_beam_order2.p, order2.data(), nb * sizeof(uint32_t)));
         RR_HIP(c, c->d_beam_order.ensure(nb));
-        if (nb) RR_HIP(c, hipMemcpy(c->d_beam_order.p, order.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (nb) RR_HIP(c, upload_table(c, c->d_beam_order.p, order.data(), nb * sizeof(uint32_t)));
     }
     }
 
@@ -420,7 +442,7 @@ int upload_tables(rr_ctx* c)
     for (size_t i = 0; i < m4.size(); i++)
         m4[i] = make_float4(c->materials[i].velocity, c->materials[i].ambient, c->materials[i].diffuse, c->materials[i].specular);
     RR_HIP(c, c->d_materials.ensure(m4.size()));
-    if (!m4.empty()) RR_HIP(c, hipMemcpy(c->d_materials.p, m4.data(), m4.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!m4.empty()) RR_HIP(c, upload_table(c, c->d_materials.p, m4.data(), m4.size() * sizeof(float4)));
     // angles of total reflection, tabulated on the device (the very asin the kernels used to call per wave-pass)
     RR_HIP(c, c->d_mat_limits.ensure(m4.size()));
     launch_mat_limits(c->d_materials.p, m4.size(), c->d_mat_limits.p, nullptr);
@@ -429,13 +451,13 @@ int upload_tables(rr_ctx* c)
     RR_HIP(c, hipStreamSynchronize(nullptr));
     RR_HIP(c, c->d_objmat.ensure(c->object_materials.size()));
     if (!c->object_materials.empty())
-        RR_HIP(c, hipMemcpy(c->d_objmat.p, c->object_materials.data(), c->object_materials.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        RR_HIP(c, upload_table(c, c->d_objmat.p, c->object_materials.data(), c->object_materials.size() * sizeof(int32_t)));
     }
 
     if (dirty & rr_ctx::D_CFG) {
     make_smear(g, c->smear, c->smear_mode);
     RR_HIP(c, c->d_smear.ensure(c->smear.size()));
-    if (!c->smear.empty()) RR_HIP(c, hipMemcpy(c->d_smear.p, c->smear.data(), c->smear.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!c->smear.empty()) RR_HIP(c, upload_table(c, c->d_smear.p, c->smear.data(), c->smear.size() * sizeof(float)));
 
     RR_HIP(c, c->d_decay.ensure((size_t)std::max(1, g.n_cells)));
     launch_decay_table(c->d_decay.p, g.n_cells, g.resolution, g.ambient_noise_energy_loss, nullptr);
@@ -453,7 +475,7 @@ int upload_tables(rr_ctx* c)
     std::vector<float> nz((size_t)c->noise_rows * A, 0.0f);
     for (size_t i = 0; i < nz.size() && i < c->noise.size(); i++) nz[i] = c->noise[i];
     RR_HIP(c, c->d_noise.ensure(nz.size()));
-    RR_HIP(c, hipMemcpy(c->d_noise.p, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
+    RR_HIP(c, upload_table(c, c->d_noise.p, nz.data(), nz.size() * sizeof(float)));
     }
     if ((dirty & (rr_ctx::D_MOTION | rr_ctx::D_CFG)) && !c->motion.empty()) {
         // one table of n_angles poses, or k tables: frame f of a batch then takes table f % k (one sweep of the antenna per frame)
@@ -461,7 +483,7 @@ int upload_tables(rr_ctx* c)
             return fail(c, -3, "rr_set_motion_poses: the number of poses must be a multiple of n_angles (one table per frame of a batch)");
         c->motion_rows = (int)(c->motion.size() / (7 * (size_t)g.n_angles));
         RR_HIP(c, c->d_motion.ensure(c->motion.size()));
-        RR_HIP(c, hipMemcpy(c->d_motion.p, c->motion.data(), c->motion.size() * sizeof(float), hipMemcpyHostToDevice));
+        RR_HIP(c, upload_table(c, c->d_motion.p, c->motion.data(), c->motion.size() * sizeof(float)));
     }
     c->motion_live = !c->motion.empty();
     const void* motion_after = c->motion_live ? (const void*)c->d_motion.p : nullptr;
@@ -1013,9 +1035,14 @@ rr_ctx* rr_create(int device)
     {   // the one angle of total reflection that does not depend on the material table
         const float4 same = make_float4(0.3f, 0.f, 0.f, 0.f);
         DevBuf<float4> m1; DevBuf<double> l1;
-        bool ok = m1.ensure(1) == hipSuccess && l1.ensure(1) == hipSuccess &&
-                  hipMemcpy(m1.p, &same, sizeof(same), hipMemcpyHostToDevice) == hipSuccess;
-        if (ok) { launch_mat_limits(m1.p, 1, l1.p, nullptr); ok = hipMemcpy(&c->limit_same, l1.p, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess; }
+        bool ok = m1.ensure(1) == hipSuccess && l1.ensure(2) == hipSuccess &&
+                  upload_table(c, m1.p, &same, sizeof(same)) == hipSuccess;
+        if (ok) {
+            launch_mat_limits(m1.p, 1, l1.p, nullptr);
+            double two[2] = {0.0, 0.0};
+            ok = hipStreamSynchronize(nullptr) == hipSuccess && read_back(c, two, l1.p, sizeof(two)) == 0;
+            c->limit_same = two[0];
+        }
         m1.release(); l1.release();
         if (!ok) { g_create_error = "rr_create: device set-up failed"; rr_destroy(c); return nullptr; }
     }

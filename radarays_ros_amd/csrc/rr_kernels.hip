@@ -1554,6 +1554,19 @@ void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int 
 __global__ void k_store_u32(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) { *dst = *src; }
 void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, src, h_dst); }
 
+// word-wise copy of a small table (either side may be page-locked host memory): the set-up uploads of rr_set_params
+__global__ __launch_bounds__(256) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy_words(const void* src, void* dst, size_t bytes, hipStream_t s)
+{
+    const size_t n = bytes / 4;
+    if (!n) return;
+    const int g = (int)std::min<size_t>(256, (n + 255) / 256);
+    hipLaunchKernelGGL(k_copy_words, dim3(g), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), n);
+}
+
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(64, (npx / 16 + 255) / 256));
