@@ -14,7 +14,9 @@
  *   per-hit math (fresnel, BRDF, smear kernels, Perlin, erfinvf):
  *       pinned to the known-answer values SURVEY.md §8c captured from the
  *       reference's compiled C++ (tests/golden/survey_kat.json), to the
- *       reference's importable python scripts (tests/golden/pyref_*.json) and,
+ *       reference's importable python scripts (tests/golden/pyref_*.json,
+ *       pyref_dense_*.npy: 11,000 Fresnel / Snell cases, pyref_brdf.npy: 3,624
+ *       cases of the BRDF lobe) and,
  *       for erfinvf/quantile, to oracle/_ref (the reference's own
  *       radar_math.h compiled as-is).
  *   loop glue (RadarCPU.cpp:156-548) and the ray cast (rmagine/Embree, not in
