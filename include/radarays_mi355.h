@@ -363,6 +363,10 @@ int rr_debug_trace(rr_ctx* ctx, const float* origs /*[n][3]*/, const float* dirs
 int rr_debug_fresnel(rr_ctx* ctx, size_t n, const float* normals /*[n][3]*/, const float* dirs /*[n][3]*/, const double* energy /*[n]*/,
                      const double* v1 /*[n]*/, const float* v2 /*[n]*/,
                      float* out_refl_dir /*[n][3]*/, double* out_refl_energy /*[n]*/, float* out_refr_dir /*[n][3]*/, double* out_refr_energy /*[n]*/);
+/* Test hook: the kernels' own back_reflection_shader (radar_algorithms.h:168-187 as RadarCPU.cpp:310-316,347-353 call it) on n
+ * independent inputs, in5 = [n][5] (incidence angle, energy, ambient, diffuse, specular); brdf_model as in rr_config.  Tests compare
+ * it with the oracle on the cases of tests/golden/pyref_brdf.npy (outputs of the reference's scripts/radarays_snell_fresnel_brdf.py). */
+int rr_debug_brdf(rr_ctx* ctx, size_t n, const float* in5 /*[n][5]*/, int brdf_model, float* out /*[n]*/);
 int rr_get_bvh_info(rr_ctx* ctx, uint64_t* n_nodes, uint64_t* n_tris, uint32_t* depth, uint32_t* stack_need);
 /* How the later-pass trace launches are sized (round 5).  A segment holds at most n_beam * 2^pass waves in pass `pass`;
  * instead of a row of 16-ray workgroups up to that bound per segment, a row is as long as earlier batches of this context

@@ -39,6 +39,7 @@ Params trace0_params(const Params& P);
 void launch_score(const uint8_t* imgs, const uint8_t* ref, size_t npx, int n_images, unsigned long long* sse, hipStream_t s);
 void launch_copy_host(const void* src, void* dst, size_t bytes, int blocks, int inflight, int xcd, hipStream_t s, int threads);
 void launch_copy_words(const void* src, void* dst, size_t bytes, hipStream_t s);
+void launch_debug_brdf(size_t n, const float* in, int model, float* out, hipStream_t s);
 void launch_store_u32(const uint32_t* src, uint32_t* h_dst, hipStream_t s);
 void launch_debug_fresnel(size_t n, const float* normals, const float* dirs, const double* energy, const double* v1, const float* v2,
                           float* out_rdir, double* out_re, float* out_tdir, double* out_te, hipStream_t s);
@@ -2241,6 +2242,28 @@ int rr_debug_fresnel(rr_ctx* c, size_t n, const float* normals, const float* dir
     if (e == hipSuccess) e = hipMemcpy(out_refr_energy, d_te.p, n * sizeof(double), hipMemcpyDeviceToHost);
     d_n.release(); d_d.release(); d_v2.release(); d_rd.release(); d_td.release(); d_e.release(); d_v1.release(); d_re.release(); d_te.release();
     if (e != hipSuccess) return fail(c, -100, std::string("rr_debug_fresnel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rr_debug_brdf(rr_ctx* c, size_t n, const float* in5, int brdf_model, float* out)
+{
+    if (!c) return -1;
+    if (n == 0) return 0;
+    if (!in5 || !out) return fail(c, -3, "rr_debug_brdf: null pointer");
+    if (brdf_model != 0 && brdf_model != 1) return fail(c, -3, "rr_debug_brdf: brdf_model must be 0 or 1");
+    RR_HIP(c, hipSetDevice(c->device));
+    DevBuf<float> d_in, d_out;
+    hipError_t e = d_in.ensure(5 * n);
+    if (e == hipSuccess) e = d_out.ensure(n);
+    if (e == hipSuccess) e = hipMemcpy(d_in.p, in5, 5 * n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_debug_brdf(n, d_in.p, brdf_model, d_out.p, c->stream);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out.p, n * sizeof(float), hipMemcpyDeviceToHost);
+    d_in.release(); d_out.release();
+    if (e != hipSuccess) return fail(c, -100, std::string("rr_debug_brdf: ") + hipGetErrorString(e));
     return 0;
 }
 

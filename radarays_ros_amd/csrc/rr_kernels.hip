@@ -720,6 +720,17 @@ __device__ inline float back_reflection_shader(float incidence_angle, float ener
     return I_total * energy;
 }
 
+// test hook (rr_debug_brdf): the shader exactly as k_shade calls it; in = [n][5] (angle, energy, ambient, diffuse, specular)
+__global__ void k_debug_brdf(size_t n, const float* __restrict__ in, int model, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = back_reflection_shader(in[5 * i], in[5 * i + 1], in[5 * i + 2], in[5 * i + 3], in[5 * i + 4], model);
+}
+void launch_debug_brdf(size_t n, const float* in, int model, float* out, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_debug_brdf, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, in, model, out);
+}
+
 // RadarCPU.cpp:410-413: time -> range bin
 __device__ inline int signal_cell(double time, double resolution)
 {

@@ -20,7 +20,7 @@ SYMBOLS = [
     "rr_simulate_batch_columns_carry_device",
     "rr_assemble_image_device", "rr_assemble_blocks_device", "rr_assemble_frames_device", "rr_simulate_device",
     "rr_simulate_material_sets_device", "rr_simulate_material_sets", "rr_simulate_batch_device", "rr_synchronize", "rr_get_stats",
-    "rr_set_stats_mode", "rr_debug_trace", "rr_debug_fresnel", "rr_get_bvh_info", "rr_get_trace_grid", "rr_get_graph_stats", "rr_set_timing_mode",
+    "rr_set_stats_mode", "rr_debug_trace", "rr_debug_fresnel", "rr_debug_brdf", "rr_get_bvh_info", "rr_get_trace_grid", "rr_get_graph_stats", "rr_set_timing_mode",
     "rr_get_kernel_time", "rr_get_kernel_samples", "rr_reserve_timing_events",
     "rr_simulate_batch_host_async", "rr_wait_host", "rr_host_alloc", "rr_host_free", "rr_copy_to_host_async", "rr_deliver_to_host_async", "rr_host_delivery_route", "rr_partition", "rr_multi_plan",
     "rr_create_multi", "rr_destroy_multi", "rr_multi_last_error", "rr_multi_device_count", "rr_multi_rccl_version", "rr_multi_ctx",
@@ -136,6 +136,7 @@ def lib():
     L.rr_get_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.rr_debug_trace.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.rr_debug_fresnel.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rr_debug_brdf.argtypes = [vp, C.c_size_t, vp, C.c_int, vp]
     L.rr_get_trace_grid.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
     L.rr_get_graph_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rr_get_bvh_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -522,6 +523,14 @@ class Context:
         self._ck(self._L.rr_debug_fresnel(self._h, n, nr.ctypes.data, d.ctypes.data, e.ctypes.data, a.ctypes.data, b.ctypes.data,
                                           rd.ctypes.data, re.ctypes.data, td.ctypes.data, te.ctypes.data))
         return rd, re, td, te
+
+    def debug_brdf(self, angle, energy, ambient, diffuse, specular, brdf_model=0):
+        """rr_debug_brdf: the kernels' back_reflection_shader on n inputs (arrays or scalars, broadcast) -> [n] f32"""
+        cols = np.broadcast_arrays(*[np.asarray(x, np.float32) for x in (angle, energy, ambient, diffuse, specular)])
+        x = np.ascontiguousarray(np.stack([c.reshape(-1) for c in cols], 1), np.float32)
+        out = np.zeros(len(x), np.float32)
+        self._ck(self._L.rr_debug_brdf(self._h, len(x), x.ctypes.data, int(brdf_model), out.ctypes.data))
+        return out
 
 
 class HostImages:

@@ -5,6 +5,8 @@
   * the per-pass history reaches the host through a kernel's stores (no hipMemcpyAsync left in a chain)
   * k_trace with the root step peeled (RR_ROOT_PRELOAD builds) is covered by the ordinary parity suite: same code path
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -276,3 +278,47 @@ def test_launch_graph_capture_while_deliveries_are_in_flight(native_lib, monkeyp
             h.close()
     assert c.host_delivery_route() == "sdma" and c.graph_stats()[0] >= 3
     c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_brdf_against_the_oracle_on_the_reference_derived_cases(native_lib, oracle):
+    """The kernels' back_reflection_shader (rr_debug_brdf = the function k_shade calls) on the 3,624 cases of
+    tests/golden/pyref_brdf.npy -- inputs whose expected values came out of the reference's own
+    scripts/radarays_snell_fresnel_brdf.py -- against (a) the oracle: both compute cosf / powf in f32, the GPU with its own libm,
+    so the results are the same float or a few ulp of the lobe apart (one ulp of the cosine times the exponent); (b) the
+    script's values themselves, by the law of tests/test_oracle_brdf_pin.py.  Plus linearity in energy and diffuse weight,
+    bit for bit (one f32 multiplication each), and the brdf_model = 1 lobe against its CPU twin."""
+    X = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pyref_brdf.npy"))
+    a, cx, w, want = X[:, 0], X[:, 1], X[:, 2], X[:, 3]
+    d = (np.float32(1.0) - a.astype(np.float32)).astype(np.float32)
+    c = native_lib.Context(0)
+    got = c.debug_brdf(w, 1.0, a, d, cx).astype(np.float64)
+    orc = np.array([oracle.back_reflection_shader(np.float32(w[i]), 1.0, float(a[i]), float(d[i]), float(cx[i])) for i in range(len(X))])
+    cw = np.cos(w)
+    lobe = (1.0 - a) * cw ** cx
+    # (a) GPU vs oracle: ulp-level differences of cosf / powf only
+    dev = np.abs(got - orc)
+    law_a = 1.5e-7 * np.maximum(orc, 1e-30) + lobe * (2.5e-7 + 1.3e-7 * cx)      # (an ulp of the cosine becomes C ulps of the lobe)
+    same = float((got.astype(np.float32) == orc.astype(np.float32)).mean())
+    print("brdf GPU vs oracle: bit-equal %.4f, max |d| %.3g" % (same, dev.max()))
+    assert same >= 0.90, same
+    assert (dev <= law_a + 1e-12).all(), (dev.max(), X[np.argmax(dev - law_a)])
+    # (b) GPU vs the script
+    tol = np.minimum(1.5e-7 + lobe * (1e-7 + 6e-8 * cx * (1.0 + 1.0 / np.maximum(cw, 1e-7))), 1.5e-7 + lobe)
+    assert (np.abs(got - want) <= tol).all()
+    # linear in the energy and in the diffuse weight: cos^C alone, then one multiplication each
+    base = c.debug_brdf(w, 1.0, 0.0, 1.0, cx)
+    for dd, e in ((0.25, 0.37), (1.7, 12.5), (0.0, 1.0)):
+        g = c.debug_brdf(w, e, a, dd, cx)
+        ref = ((a.astype(np.float32) + np.float32(dd) * base).astype(np.float32) * np.float32(e)).astype(np.float32)
+        assert np.array_equal(g, ref), (dd, e)
+    # the build's own lobe (brdf_model = 1) against its CPU twin: same operation order, the GPU's sincosf / sqrtf
+    import ctypes as C_
+    L = oracle.lib()
+    L.orc_back_reflection_shader_model.restype = C_.c_float
+    L.orc_back_reflection_shader_model.argtypes = [C_.c_float] * 5 + [C_.c_int32]
+    g1 = c.debug_brdf(w, 1.0, a, d, cx, brdf_model=1).astype(np.float64)
+    o1 = np.array([L.orc_back_reflection_shader_model(np.float32(w[i]), 1.0, float(a[i]), float(d[i]), float(cx[i]), 1) for i in range(len(X))])
+    assert np.abs(g1 - o1).max() <= 2e-6, np.abs(g1 - o1).max()
+    with pytest.raises(native_lib.RRError, match="brdf_model"):
+        c.debug_brdf(w[:4], 1.0, 0.5, 0.5, 10.0, brdf_model=2)
