@@ -11,7 +11,7 @@ with injected per-column offsets (fresh row per frame).  `--workload` selects th
 
 A step = ONE pass over the 16-pose trajectory: every GPU finishes 16 polar images per step, rendered as two
 batches of 8 poses (one set of launches each; `--frames-per-rank` poses per batch, `--batches-per-step` batches),
-batches in flight on 4 streams.  Mesh, BVH, parameters and beam samples are resident in HBM before the timed
+3 batches in flight on 3 streams (`--slots`; 4 where a batch is fewer than 8 frames).  Mesh, BVH, parameters and beam samples are resident in HBM before the timed
 region; poses are 7 floats passed as kernel arguments.  Timing bracket = the reference's stopwatch
 (RadarCPU.cpp:147-148 -> :550).
 
@@ -340,11 +340,16 @@ def main(argv=None):
     ap.add_argument("--self-launch", action="store_true",
                     help="go through the torch.distributed.run child even for N = 1 (exercises the launcher path on a one-GPU box)")
     ap.add_argument("--force-slots", action="store_true", help="run the N>1 step loop (with its collective) on one rank (debug)")
-    ap.add_argument("--slots", type=int, default=4, help="batches in flight (streams + buffer sets); RR_LANES must be >= slots")
+    ap.add_argument("--slots", type=int, default=None,
+                    help="batches in flight (streams + buffer sets; RR_LANES must be >= slots).  Default: 3 for batches of >= 8 frames per GPU, "
+                         "else 4 -- the fewest that hold the rate (round 6, profiles/r06_experiments.txt: the target reads the same images/s "
+                         "from 2 to 6; a launch's live duration, and with it roofline.frac, only says how many batches share the chip)")
     ap.add_argument("--frames-per-rank", type=int, default=8,
                     help="frames each GPU finishes per batch (one set of launches); a batch = N x this many frames")
     ap.add_argument("--batches-per-step", type=int, default=2, help="batches per step (default: 2 x 8 = the 16-pose trajectory)")
     args = ap.parse_args(argv)
+    if args.slots is None:
+        args.slots = 3 if (args.frames_per_rank >= 8 and not args.strong) else 4
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -583,7 +588,8 @@ def main(argv=None):
                    "ms_per_step": round(1e3 * (th1 - th0) / args.steps, 4),
                    "what": "same steps, every mono8 image assembled and LEFT IN HBM (no D2H copy in the timed region): the "
                            "`value` of rounds 1-4"}
-        one = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, 0, 1, dev, frames_per_rank=1, n_slots=args.slots)
+        sp_slots = max(4, args.slots)               # single-frame launch sets want four in flight (2 / 3 / 4: 2,980 / 3,710 / 4,180 images/s)
+        one = AzimuthShard(ctx, cfg.n_cells, params.N_ANGLES, 0, 1, dev, frames_per_rank=1, n_slots=sp_slots)
         n1 = max(args.steps, 16)
         prewarm(lambda k: one.step([poses[k % len(poses)]], None))
         tc.synchronize()
@@ -594,7 +600,7 @@ def main(argv=None):
         ts1 = time.perf_counter()
         single = {"value": round(n1 / (ts1 - ts0), 2), "unit": "images/s", "frames_per_launch_set": 1,
                   "ms_per_image": round(1e3 * (ts1 - ts0) / n1, 4), "images": n1,
-                  "what": "one pose per set of launches, %d in flight on %d streams, image left in HBM" % (args.slots, args.slots)}
+                  "what": "one pose per set of launches, %d in flight on %d streams, image left in HBM" % (sp_slots, sp_slots)}
         one.close()
         # the reference's own call shape (radar_simulator.cpp:197-212): ONE synchronous simulate() per frame, image in host memory
         img = np.zeros((cfg.n_cells, params.N_ANGLES), np.uint8)
