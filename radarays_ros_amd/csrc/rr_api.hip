@@ -1523,12 +1523,14 @@ int rr_deliver_to_host_async(rr_ctx* c, const void* d_src, void* h_dst, size_t b
     SdmaCopier* sd = visible ? sdma_of(c, d_src) : nullptr;
     uint64_t job = 0;
     if (sd) {
-        RR_HIP(c, hipEventRecord(ev, s));                  // the copy starts once the stream has got here
+        const hipError_t e = hipEventRecord(ev, s);        // the copy starts once the stream has got here
+        if (e != hipSuccess) { c->delivery_events.push_back(ev); RR_HIP(c, e); }
         job = sdma_submit(sd, ev, d_src, h_dst, bytes);
     } else {
         const int rc = copy_out(c, d_src, h_dst, bytes, visible, s);
         if (rc) { c->delivery_events.push_back(ev); return rc; }
-        RR_HIP(c, hipEventRecord(ev, s));                  // ... is complete once the stream has got here
+        const hipError_t e = hipEventRecord(ev, s);        // ... is complete once the stream has got here
+        if (e != hipSuccess) { c->delivery_events.push_back(ev); RR_HIP(c, e); }
     }
     c->deliveries.push_back({ h_dst, job, ev });
     return 0;
