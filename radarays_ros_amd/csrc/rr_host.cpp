@@ -362,11 +362,9 @@ int rr_mesh_reorder_objects(rr_mesh* m, const char* const* order, size_t n_order
         new_id[hit] = next++;
     }
     for (size_t i = 0; i < n; i++) if (new_id[i] == 0xFFFFFFFFu) new_id[i] = next++;      // the unlisted ones keep their relative order behind the listed
-    for (size_t f = 0; f < m->n_faces; f++) {
-        const uint32_t o = m->face_object_id[f];
-        if ((size_t)o >= n) { set_err(err, err_len, "rr_mesh_reorder_objects: face_object_id out of range"); return -3; }
-        m->face_object_id[f] = new_id[o];
-    }
+    for (size_t f = 0; f < m->n_faces; f++)          // (checked before anything is changed: a refusal leaves the mesh as it was)
+        if ((size_t)m->face_object_id[f] >= n) { set_err(err, err_len, "rr_mesh_reorder_objects: face_object_id out of range"); return -3; }
+    for (size_t f = 0; f < m->n_faces; f++) m->face_object_id[f] = new_id[m->face_object_id[f]];
     std::vector<char*> names(n);
     for (size_t i = 0; i < n; i++) names[new_id[i]] = m->object_names[i];
     for (size_t i = 0; i < n; i++) m->object_names[i] = names[i];

@@ -16,6 +16,54 @@ static uint64_t g_s = 0x243F6A8885A308D3ull;
 static uint32_t rnd() { g_s = g_s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(g_s >> 33); }
 static void put(const std::string& path, const std::string& bytes) { std::ofstream f(path, std::ios::binary); f.write(bytes.data(), (std::streamsize)bytes.size()); }
 
+// rr_mesh_reorder_objects (round 6) on a loaded mesh: the reversed order of its names must permute the ids and the names
+// together (face f keeps its object's NAME) and nothing else; an unknown name, a name listed twice, a null name and a mesh
+// without names are refused with a message and leave the mesh as it was.  Duplicate names in the mesh itself (possible in a
+// damaged file) are refused too.
+static int reorder_check(rr_mesh& m, const char* what)
+{
+    int bad = 0;
+    char err[200] = "";
+    if (!m.object_names) {
+        const char* one[1] = { "x" };
+        if (rr_mesh_reorder_objects(&m, one, 1, err, sizeof(err)) == 0 || !err[0]) { std::printf("%s: reorder accepted a mesh without names\n", what); bad++; }
+        if (rr_mesh_reorder_objects(&m, nullptr, 0, err, sizeof(err)) != 0) { std::printf("%s: an empty order was refused\n", what); bad++; }
+        return bad;
+    }
+    const size_t n = m.n_objects;
+    std::vector<std::string> before_name(m.n_faces);
+    for (size_t f = 0; f < m.n_faces; f++) before_name[f] = m.object_names[m.face_object_id[f]];
+    const std::vector<uint32_t> before_id(m.face_object_id, m.face_object_id + m.n_faces);
+    bool dup = false;
+    for (size_t i = 0; i < n && !dup; i++) for (size_t j = i + 1; j < n; j++) if (std::strcmp(m.object_names[i], m.object_names[j]) == 0) { dup = true; break; }
+    std::vector<std::string> keep(n);
+    for (size_t i = 0; i < n; i++) keep[i] = m.object_names[n - 1 - i];
+    std::vector<const char*> rev(n);
+    for (size_t i = 0; i < n; i++) rev[i] = keep[i].c_str();
+    const int rc = rr_mesh_reorder_objects(&m, rev.data(), n, err, sizeof(err));
+    if (dup) {
+        if (rc == 0) { std::printf("%s: duplicate object names were accepted\n", what); bad++; }
+        else if (!std::equal(before_id.begin(), before_id.end(), m.face_object_id)) { std::printf("%s: a refused reorder changed the ids\n", what); bad++; }
+        return bad;
+    }
+    if (rc != 0) { std::printf("%s: the reversed order was refused: %s\n", what, err); return 1; }
+    for (size_t f = 0; f < m.n_faces; f++) {
+        if (m.face_object_id[f] >= n || before_name[f] != m.object_names[m.face_object_id[f]]) { std::printf("%s: face %zu lost its object's name\n", what, f); bad++; break; }
+        if (m.face_object_id[f] != (uint32_t)(n - 1 - before_id[f])) { std::printf("%s: face %zu: id not reversed\n", what, f); bad++; break; }
+    }
+    for (size_t i = 0; i < n; i++) if (keep[i] != m.object_names[i]) { std::printf("%s: names not in the requested order\n", what); bad++; break; }
+    const std::vector<uint32_t> now(m.face_object_id, m.face_object_id + m.n_faces);
+    const char* unknown[1] = { "\x01 no such object" };
+    const char* twice[2] = { rev[0], rev[0] };
+    const char* nul[1] = { nullptr };
+    if (rr_mesh_reorder_objects(&m, unknown, 1, err, sizeof(err)) == 0) { std::printf("%s: an unknown name was accepted\n", what); bad++; }
+    if (n && rr_mesh_reorder_objects(&m, twice, 2, err, sizeof(err)) == 0) { std::printf("%s: a name listed twice was accepted\n", what); bad++; }
+    if (rr_mesh_reorder_objects(&m, nul, 1, err, sizeof(err)) == 0) { std::printf("%s: a null name was accepted\n", what); bad++; }
+    if (rr_mesh_reorder_objects(&m, rev.data(), 1, nullptr, 0) != 0 && n) { /* a partial order is fine; no error buffer is fine */ std::printf("%s: a partial order was refused\n", what); bad++; }
+    if (!std::equal(now.begin(), now.end(), m.face_object_id) && n <= 1) { std::printf("%s: ids changed by no-op orders\n", what); bad++; }
+    return bad;
+}
+
 int main(int argc, char** argv)
 {
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
@@ -71,6 +119,7 @@ int main(int argc, char** argv)
         const bool ok = rc == 0 && m.n_verts == c.nv && m.n_faces == c.nf;
         std::printf("%s: %s %s\n", c.name, ok ? "ok" : "FAILED", err);
         fails += !ok;
+        if (rc == 0) fails += reorder_check(m, c.name);
         rr_free_mesh(&m); rr_free_mesh(&m);          // twice: must be harmless
     }
     // ---- damaged files: error code or a mesh whose indices are in range, never a crash ----------------------------
@@ -93,6 +142,7 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < 3 * m.n_faces; i++) if (m.faces[i] >= m.n_verts) { std::printf("iteration %d: index out of range in an accepted mesh\n", it); fails++; break; }
             for (size_t i = 0; i < m.n_faces; i++) if (m.face_object_id[i] >= m.n_objects) { std::printf("iteration %d: object id out of range\n", it); fails++; break; }
             if (m.object_names) for (size_t i = 0; i < m.n_objects; i++) if (!m.object_names[i] || std::strlen(m.object_names[i]) > b.size()) { std::printf("iteration %d: bad object name\n", it); fails++; break; }
+            if (it % 8 == 0) fails += reorder_check(m, "damaged file");
             rr_free_mesh(&m);
         } else {
             n_err++;
